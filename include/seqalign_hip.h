@@ -1,0 +1,125 @@
+/*
+ * seqalign_hip.h -- C-ABI of libseqalign_hip.so, the MI355X (gfx950) DP alignment engine.
+ *
+ * Drop-in boundary for the reference's three hot-path entry points.  The reference
+ * (bibymaths/SequenceAligner) has no FFI; its seam is three free functions inside
+ * src/main.cpp that take two residue strings plus the globals GAP_OPEN/GAP_EXTEND and
+ * write result files.  Each sa_* entry point below replaces the fill + traceback part
+ * of one of them and returns what the reference's writers need (score, end cell and
+ * the traceback op list); see INTEGRATION.md for the binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no exceptions across the boundary; every call returns SA_OK (0) or a
+ *     negative SA_ERR_* code, sa_last_error(ctx) gives the message
+ *   - inputs are caller-owned host buffers of raw residue bytes (exactly what the
+ *     reference's processFasta produces, main.cpp:290-308); they may be freed as soon
+ *     as the call returns
+ *   - outputs inside sa_result are library-owned host buffers, released by
+ *     sa_free_result()
+ *   - one sa_ctx per GPU; a ctx is not thread-safe; device workspaces are cached in
+ *     the ctx between calls (the first call at a given size allocates)
+ *   - x = query = rows (length m), y = target = columns (length n); matrix cells are
+ *     1-based (i, j) exactly as in the reference
+ *   - ops[]: one byte per traceback move in traceback order (end cell -> start cell):
+ *       0 = diagonal  x[i-1] over y[j-1]      (reference pointer 'M' / LCS 'D')
+ *       1 = left      '-'    over y[j-1]      (reference pointer 'E','e' / LCS 'L')
+ *       2 = up        x[i-1] over '-'         (reference pointer 'F','f' / LCS 'U')
+ */
+#ifndef SEQALIGN_HIP_H
+#define SEQALIGN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SA_OK 0
+#define SA_ERR_INVALID_CODE (-2) /* residue outside the scoring alphabet: the reference throws
+                                    "Invalid DNA code: x,y" / "Invalid protein code: x,y"
+                                    (main.cpp:120-121, 134-136); bad_x/bad_y carry x,y */
+#define SA_ERR_NOMEM (-3)
+#define SA_ERR_HIP (-4)
+#define SA_ERR_ARG (-5)
+#define SA_ERR_UNSUPPORTED (-6)
+
+#define SA_MODE_DNA 0     /* EDNAFULL via char2idx, main.cpp:57-78, 117-123 */
+#define SA_MODE_PROTEIN 1 /* EBLOSUM62 via prot_idx, main.cpp:81-109, 131-138 */
+
+/* flags */
+#define SA_FLAG_KEEP_DP 1u  /* also return the full (m+1)x(n+1) int32 S (or LCS L) matrix:
+                               what --binary/--txt dump (main.cpp:825-831, 1364-1368, 1686-1691) */
+#define SA_FLAG_NO_TRACEBACK 2u /* score (and SW end cell) only */
+
+typedef struct sa_ctx sa_ctx;
+
+/* Scoring = the reference's ScoreFn (main.cpp:38) + GAP_OPEN/GAP_EXTEND (main.cpp:41-43). */
+typedef struct {
+  double gap_open;       /* negative; added as int+double and truncated per op (main.cpp:603) */
+  double gap_extend;
+  const int8_t* sub;     /* alpha x alpha substitution scores, row-major, sub[ix*alpha+iy] */
+  int32_t alpha;         /* <= 32 */
+  const uint8_t* idx256; /* residue byte -> table index, 255 = invalid (the reference throws) */
+} sa_scoring;
+
+typedef struct {
+  int64_t score;            /* NW: S[m][n] (main.cpp:766); SW: best S (main.cpp:1124); LCS: L[m][n] */
+  int64_t end_i, end_j;     /* cell where the traceback starts: NW/LCS (m,n); SW first row-major max */
+  int64_t start_i, start_j; /* cell where it stopped: NW/LCS (0,0); SW the 'X' cell (main.cpp:1233) */
+  uint8_t* ops;             /* n_ops traceback moves, end -> start */
+  int64_t n_ops;
+  int32_t* dp;              /* SA_FLAG_KEEP_DP: (m+1)*(n+1) row-major, else NULL */
+  unsigned char bad_x, bad_y; /* SA_ERR_INVALID_CODE: the pair the reference would report */
+  /* device-side timing of the last call, milliseconds (HIP events on the ctx stream) */
+  float fill_ms;            /* H2D of sequences + profile build + fill kernels */
+  float traceback_ms;       /* traceback kernel + D2H of the op list */
+  float kernel_fill_ms;     /* fill kernels only */
+  int32_t n_launches;       /* fill kernel launches */
+  int32_t rows_per_lane;    /* K chosen for this call */
+  int32_t tile_steps;       /* C chosen for this call */
+} sa_result;
+
+/* ---- lifetime ---- */
+sa_ctx* sa_create(int device_id);           /* NULL on failure (no GPU / no gfx950 code object) */
+void sa_destroy(sa_ctx* ctx);
+const char* sa_last_error(const sa_ctx* ctx);
+int sa_set_stream(sa_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = the ctx's own stream */
+void sa_free_result(sa_result* r);
+/* frees the ctx's cached device workspaces (they are re-allocated on demand) */
+int sa_release_workspace(sa_ctx* ctx);
+/* tuning overrides, 0 = automatic: rows per lane K in {1,2,4,8}, tile steps C multiple of 64 */
+int sa_set_tuning(sa_ctx* ctx, int rows_per_lane, int tile_steps);
+
+/* The reference's two built-in scoring schemes with default penalties -5/-1
+ * (main.cpp:41-43): EDNAFULL indexed by char2idx (including its index-order quirk) and
+ * EBLOSUM62 indexed by prot_idx.  The returned struct is static; copy it to change gaps. */
+const sa_scoring* sa_builtin_scoring(int mode);
+
+/* ---- hot path ---- */
+
+/* replaces the fill + traceback of globalalign(), main.cpp:691-818 */
+int sa_nw(sa_ctx* ctx, const uint8_t* x, int64_t m, const uint8_t* y, int64_t n,
+          const sa_scoring* sc, uint32_t flags, sa_result* out);
+
+/* replaces both fill passes + traceback of localalign(), main.cpp:1099-1128, 1182-1265 */
+int sa_sw(sa_ctx* ctx, const uint8_t* x, int64_t m, const uint8_t* y, int64_t n,
+          const sa_scoring* sc, uint32_t flags, sa_result* out);
+
+/* replaces the fill + traceback of lcs(), main.cpp:1575-1640 (raw byte equality) */
+int sa_lcs(sa_ctx* ctx, const uint8_t* x, int64_t m, const uint8_t* y, int64_t n,
+           uint32_t flags, sa_result* out);
+
+/* Many independent pairs, score + end cell only: the first fill pass of localalign()
+ * (main.cpp:1099-1128) per pair.  Pair k is x = seqs[off_x[k] .. +len_x[k]),
+ * y = seqs[off_y[k] .. +len_y[k]).  Outputs are caller-owned arrays of n_pairs.
+ * A pair with an invalid residue gets score = INT32_MIN and the call returns
+ * SA_ERR_INVALID_CODE after finishing the other pairs. */
+int sa_sw_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x,
+                const int64_t* off_y, const int32_t* len_y, int64_t n_pairs,
+                const sa_scoring* sc, int32_t* score, int32_t* end_i, int32_t* end_j,
+                float* kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEQALIGN_HIP_H */

@@ -1,0 +1,426 @@
+// sa_kernels.h -- CDNA4 (gfx950) device code of the DP alignment engine.
+//
+// One wavefront (64 lanes) owns a STRIP of 64*K consecutive rows; lane l owns the K rows
+// [l*K, l*K+K) of the strip and sweeps the columns with a one-column skew per lane
+// (lane l is at column c = t - l at strip-local step t), i.e. the wave walks an
+// anti-diagonal.  The cell dependencies that cross lanes (H and F of the row above, the
+// target symbol) move one lane down per step with DPP wave_shr:1 -- they never touch
+// memory.  The strip's bottom row (H,F per column) is collected in a register that is
+// rotated with DPP wave_shl:1 and flushed coalesced every 64 steps; the strip below reads
+// it the same way.  The query profile of the strip is staged in LDS as
+// prof[symbol][lane] (one dword, or two for K=8, holding the lane's K substitution
+// scores), so a lane's read hits bank == lane whatever symbol it looks up: conflict free.
+// Direction codes are packed 2 bits/cell, 16 steps per dword, and written as one
+// 16*K-byte contiguous piece per lane (1 KiB..2 KiB contiguous per wave instruction).
+//
+// The matrix is cut into TILES = (strip s) x (C consecutive global steps); tile (s,q)
+// covers global steps [q*C, q*C+C) where global step = strip-local step + 64*s.  Tile
+// (s,q) depends only on tiles (s-1,q), (s-1,q-1) and (s,q-1), so launch d runs every
+// tile with s+q == d and stream order is the only synchronisation.
+//
+// Recurrences restate the reference exactly (see DESIGN.md for the proof obligations):
+//   NW  main.cpp:622-672   SW  main.cpp:939-1013   LCS  main.cpp:1577-1587
+#pragma once
+#include <hip/hip_runtime.h>
+#include <climits>
+#include <cstdint>
+
+namespace sa {
+
+constexpr int kNeg = INT_MIN / 2;  // main.cpp:703-704
+enum { KIND_NW = 0, KIND_SW = 1, KIND_LCS = 2 };
+
+struct FillArgs {
+  int m, n;   // rows, columns
+  int S, C;   // strips, steps per tile (multiple of 64)
+  int W;      // trace dwords per (lane,k) per strip
+  int go, ge; // integer gap penalties (negative)
+  int alpha;  // profile symbols
+  int NP;     // length of one bottom-row ring buffer
+  const uint8_t* yenc;   // NW/SW: table index per column; LCS: raw byte.  Padded with zeros.
+  const uint32_t* prof;  // NW/SW: [S][alpha][64][PW] dwords
+  const uint8_t* xpad;   // LCS: raw query bytes padded to S*64*K
+  const int* colb;       // H[i][0], i = 0 .. S*64*K
+  int* botH;             // [2][NP]  bottom row H of strip s lives in buffer s&1, index p = c+64
+  int* botF;             // [2][NP]
+  int* state;            // [S][NF][64] lane state carried from tile to tile
+  uint32_t* trace;       // [S][W][64][K]
+  int* rowbest;          // SW: best score per row
+  int* rowbestc;         // SW: first column (0-based) attaining it
+  int* score_out;        // NW/LCS: H[m][n]
+  int d, s_lo;           // launch index, first strip of this launch
+};
+
+__device__ __forceinline__ int dpp_shr1(int old, int src) {  // lane l <- src of lane l-1, lane 0 <- old
+  return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ int dpp_shl1(int old, int src) {  // lane l <- src of lane l+1, lane 63 <- old
+  return __builtin_amdgcn_update_dpp(old, src, 0x130, 0xf, 0xf, false);
+}
+
+template <int KIND, int K>
+struct Geo {
+  static constexpr int PW = (K <= 4) ? 1 : K / 4;  // profile dwords per (symbol, lane)
+  static constexpr int ROWB = 64 * PW * 4;         // LDS bytes per symbol
+  // lane-state fields carried between tiles
+  static constexpr int NF = (KIND == KIND_LCS) ? K + 3 : (KIND == KIND_SW ? 4 * K + 4 : 2 * K + 4);
+};
+
+template <int KIND, int K>
+struct Lane {
+  int H[K];      // H of the cell to the left, per owned row
+  int E[K];      // E of the cell to the left (unused for LCS)
+  int passH;     // H of the lane's bottom row, handed to the lane below at the next step
+  int passF;
+  int ypass;     // target symbol handed down
+  int dprev;     // H received from above at the previous step = diagonal of row 0
+  int best[K];   // SW running best per row
+  int bestc[K];  // SW first column attaining it
+};
+
+// One skewed step of one lane: K cells of column c.
+template <int KIND, int K, bool BND>
+__device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF, int& yb, int& obH, int& obF,
+                                          uint32_t (&tacc)[K], const int u, const char* ldsLane,
+                                          const uint32_t (&xr)[K], const int go, const int ge, const int c,
+                                          const int n) {
+  using G = Geo<KIND, K>;
+  int up = dpp_shr1(ibH, st.passH);
+  int uf = 0;
+  if (KIND != KIND_LCS) uf = dpp_shr1(ibF, st.passF);
+  const int yv = dpp_shr1(yb, st.ypass);
+  ibH = dpp_shl1(ibH, ibH);
+  if (KIND != KIND_LCS) ibF = dpp_shl1(ibF, ibF);
+  yb = dpp_shl1(yb, yb);
+
+  uint32_t pw[G::PW];
+  if (KIND != KIND_LCS) {
+    if (G::PW == 1) {
+      pw[0] = *reinterpret_cast<const uint32_t*>(ldsLane + yv);
+    } else {
+      const uint2 t = *reinterpret_cast<const uint2*>(ldsLane + yv);
+      pw[0] = t.x;
+      pw[G::PW - 1] = t.y;
+    }
+  }
+  int diag = st.dprev;
+  st.dprev = up;
+  st.ypass = yv;
+  const bool act = BND ? (c >= 0 && c < n) : true;
+  int f_last = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int left = st.H[k];
+    int h, code;
+    if (KIND == KIND_LCS) {
+      const bool eq = (xr[k] == (uint32_t)yv);
+      h = eq ? diag + 1 : max(up, left);
+      code = eq ? 0 : (up >= left ? 2 : 1);
+    } else {
+      const int sg = (int)(int8_t)(pw[k / 4] >> (8 * (k & 3)));
+      int f = max(up + go, uf + ge);
+      int e = max(left + go, st.E[k] + ge);
+      int mv = diag + sg;
+      if (KIND == KIND_SW) {
+        f = max(f, 0);
+        e = max(e, 0);
+        mv = max(mv, 0);
+      }
+      const int t = max(e, f);
+      h = max(mv, t);
+      code = (mv >= t) ? 0 : (e >= f ? 1 : 2);
+      if (KIND == KIND_SW) code = (h == 0) ? 3 : code;
+      if (BND) {
+        e = act ? e : st.E[k];
+        f = act ? f : st.passF;
+      }
+      st.E[k] = e;
+      uf = f;
+      f_last = f;
+    }
+    if (BND) h = act ? h : left;
+    if (KIND == KIND_SW) {
+      const bool better = BND ? (act && h > st.best[k]) : (h > st.best[k]);
+      st.best[k] = better ? h : st.best[k];
+      st.bestc[k] = better ? c : st.bestc[k];
+    }
+    tacc[k] |= (uint32_t)code << (2 * u);
+    diag = left;
+    st.H[k] = h;
+    up = h;
+  }
+  st.passH = st.H[K - 1];
+  if (KIND != KIND_LCS) st.passF = BND ? (act ? f_last : st.passF) : f_last;
+  obH = dpp_shl1(st.passH, obH);
+  if (KIND != KIND_LCS) obF = dpp_shl1(st.passF, obF);
+}
+
+template <int K>
+__device__ __forceinline__ void store_trace(uint32_t* dst, const uint32_t (&t)[K]) {
+  if (K == 1) {
+    dst[0] = t[0];
+  } else if (K == 2) {
+    *reinterpret_cast<uint2*>(dst) = make_uint2(t[0], t[1]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; k += 4) *reinterpret_cast<uint4*>(dst + k) = make_uint4(t[k], t[k + 1], t[k + 2], t[k + 3]);
+  }
+}
+
+// 64 steps of one strip (one bottom-row hand-off in, one out).
+template <int KIND, int K, bool BND>
+__device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, const int s, const int Tb,
+                                          const int lane, const char* ldsLane, const uint32_t (&xr)[K]) {
+  using G = Geo<KIND, K>;
+  const int* rdH = a.botH + (size_t)((s & 1) ^ 1) * a.NP;
+  const int* rdF = a.botF + (size_t)((s & 1) ^ 1) * a.NP;
+  int* wrH = a.botH + (size_t)(s & 1) * a.NP;
+  int* wrF = a.botF + (size_t)(s & 1) * a.NP;
+  int ibH = rdH[Tb + 64 + lane];
+  int ibF = (KIND != KIND_LCS) ? rdF[Tb + 64 + lane] : 0;
+  int yb = a.yenc[Tb + lane];
+  if (KIND != KIND_LCS) yb *= G::ROWB;
+  int obH = 0, obF = 0;
+  uint32_t* tdst = a.trace + (((size_t)s * a.W + (Tb >> 4)) * 64 + lane) * K;
+#pragma unroll 1
+  for (int sub = 0; sub < 4; ++sub) {
+    uint32_t tacc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) tacc[k] = 0;
+    const int cbase = Tb + 16 * sub - lane;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      lane_step<KIND, K, BND>(st, ibH, ibF, yb, obH, obF, tacc, u, ldsLane, xr, a.go, a.ge, cbase + u, a.n);
+    store_trace<K>(tdst, tacc);
+    tdst += 64 * K;
+  }
+  wrH[Tb + 1 + lane] = obH;
+  if (KIND != KIND_LCS) wrF[Tb + 1 + lane] = obF;
+}
+
+template <int KIND, int K>
+__global__ void __launch_bounds__(64) fill_tile(const FillArgs a) {
+  using G = Geo<KIND, K>;
+  extern __shared__ uint32_t lds[];
+  const int lane = threadIdx.x;
+  const int s = a.s_lo + blockIdx.x;
+  const int q = a.d - s;
+  const int qmin = (64 * s) / a.C;
+  const int qmax = (64 * s + a.n + 62) / a.C;
+  if (s >= a.S || q < qmin || q > qmax) return;
+  const int T0 = q * a.C - 64 * s;  // strip-local step at the tile start (<0: padding before the strip starts)
+  const int rowg = s * 64 + lane;   // global row-group index
+  const int r0 = rowg * K;          // first owned row (0-based)
+
+  uint32_t xr[K];
+  if (KIND == KIND_LCS) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) xr[k] = a.xpad[(size_t)r0 + k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) xr[k] = 0;
+    const uint32_t* gp = a.prof + (size_t)s * a.alpha * 64 * G::PW;
+    for (int i = lane; i < a.alpha * 64 * G::PW; i += 64) lds[i] = gp[i];
+    __syncthreads();
+  }
+  const char* ldsLane = reinterpret_cast<const char*>(lds) + lane * 4 * G::PW;
+
+  Lane<KIND, K> st;
+  int* sp = a.state + ((size_t)s * G::NF) * 64 + lane;
+  if (q == qmin) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      st.H[k] = a.colb[r0 + k + 1];
+      st.E[k] = (KIND == KIND_NW) ? kNeg : 0;
+      st.best[k] = 0;
+      st.bestc[k] = -1;
+    }
+    st.passH = st.H[K - 1];
+    st.passF = (KIND == KIND_NW) ? kNeg : 0;
+    st.ypass = 0;
+    st.dprev = a.colb[r0];
+  } else {
+    int f = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) st.H[k] = sp[64 * f++];
+    if (KIND != KIND_LCS) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) st.E[k] = sp[64 * f++];
+    }
+    st.passH = sp[64 * f++];
+    if (KIND != KIND_LCS) st.passF = sp[64 * f++];
+    st.ypass = sp[64 * f++];
+    st.dprev = sp[64 * f++];
+    if (KIND == KIND_SW) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) st.best[k] = sp[64 * f++];
+#pragma unroll
+      for (int k = 0; k < K; ++k) st.bestc[k] = sp[64 * f++];
+    }
+  }
+
+#pragma unroll 1
+  for (int b = 0; b < a.C / 64; ++b) {
+    const int Tb = T0 + 64 * b;
+    if (Tb < 0) continue;
+    if (Tb >= a.n + 63) break;
+    const bool interior = (Tb >= 64) && (Tb + 63 < a.n);
+    if (interior)
+      run_block<KIND, K, false>(st, a, s, Tb, lane, ldsLane, xr);
+    else
+      run_block<KIND, K, true>(st, a, s, Tb, lane, ldsLane, xr);
+  }
+
+  if (q == qmax) {
+    if (KIND == KIND_SW) {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (r0 + k < a.m) {
+          a.rowbest[r0 + k] = st.best[k];
+          a.rowbestc[r0 + k] = st.bestc[k];
+        }
+    } else if (s == a.S - 1) {
+      const int rl = a.m - 1;
+      if (rl / K == rowg) {
+#pragma unroll
+        for (int k = 0; k < K; ++k)
+          if (k == rl % K) *a.score_out = st.H[k];
+      }
+    }
+  } else {
+    int f = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) sp[64 * f++] = st.H[k];
+    if (KIND != KIND_LCS) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) sp[64 * f++] = st.E[k];
+    }
+    sp[64 * f++] = st.passH;
+    if (KIND != KIND_LCS) sp[64 * f++] = st.passF;
+    sp[64 * f++] = st.ypass;
+    sp[64 * f++] = st.dprev;
+    if (KIND == KIND_SW) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) sp[64 * f++] = st.best[k];
+#pragma unroll
+      for (int k = 0; k < K; ++k) sp[64 * f++] = st.bestc[k];
+    }
+  }
+}
+
+// ---- query profile: prof[s][sym][lane] = the lane's K substitution scores for `sym` ----
+// xidx is the table index per query residue (padded rows get score 0).
+template <int K>
+__global__ void build_profile(const uint8_t* __restrict__ xidx, int m, const int8_t* __restrict__ sub, int alpha,
+                              int S, uint32_t* __restrict__ prof) {
+  constexpr int PW = (K <= 4) ? 1 : K / 4;
+  const size_t total = (size_t)S * alpha * 64;
+  for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (size_t)gridDim.x * blockDim.x) {
+    const int lane = (int)(g & 63);
+    const int sym = (int)((g >> 6) % alpha);
+    const int s = (int)((g >> 6) / alpha);
+    const int r0 = (s * 64 + lane) * K;
+    uint32_t w[PW];
+#pragma unroll
+    for (int i = 0; i < PW; ++i) w[i] = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      int v = 0;
+      if (r0 + k < m) v = sub[(int)xidx[r0 + k] * alpha + sym];
+      w[k / 4] |= (uint32_t)(uint8_t)(int8_t)v << (8 * (k & 3));
+    }
+#pragma unroll
+    for (int i = 0; i < PW; ++i) prof[g * PW + i] = w[i];
+  }
+}
+
+// ---- SW: reduce per-row bests to the first row-major maximum (main.cpp:1124-1127) ----
+__global__ void sw_reduce_max(const int* __restrict__ rowbest, int m, int* __restrict__ best) {
+  int v = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) v = max(v, rowbest[i]);
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(best, v);
+}
+__global__ void sw_reduce_pos(const int* __restrict__ rowbest, const int* __restrict__ rowbestc, int m,
+                              const int* __restrict__ best, unsigned long long* __restrict__ pos) {
+  const int b = *best;
+  if (b <= 0) return;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
+    if (rowbest[i] == b) atomicMin(pos, ((unsigned long long)(uint32_t)(i + 1) << 32) | (uint32_t)(rowbestc[i] + 1));
+}
+
+// ---- traceback ----
+struct TraceArgs {
+  int kind, m, n, K, W;
+  const uint32_t* trace;
+  const int* sw_best;                  // SW: best score (device)
+  const unsigned long long* sw_pos;    // SW: (i<<32)|j of the end cell (device)
+  uint8_t* ops;                        // out: one byte per move
+  long long* hdr;                      // out: n_ops, end_i, end_j, start_i, start_j
+};
+
+// direction code of matrix cell (i,j), 1-based, as stored by fill_tile
+__device__ __forceinline__ size_t trace_word_index(int i, int j, int K, int W, int& shift) {
+  const int r = i - 1, c = j - 1;
+  const int g = r / K, k = r - g * K;
+  const int s = g >> 6, l = g & 63;
+  const int t = c + l;
+  shift = 2 * (t & 15);
+  return (((size_t)s * W + (t >> 4)) * 64 + l) * K + k;
+}
+
+// v1 walker: one lane chases the pointers through global memory, re-using the current dword.
+__global__ void traceback_walk(const TraceArgs a) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  int i = a.m, j = a.n;
+  if (a.kind == KIND_SW) {
+    if (*a.sw_best <= 0) {
+      i = j = 0;
+    } else {
+      const unsigned long long p = *a.sw_pos;
+      i = (int)(p >> 32);
+      j = (int)(p & 0xffffffffu);
+    }
+  }
+  a.hdr[1] = i;
+  a.hdr[2] = j;
+  long long nops = 0;
+  size_t cur_idx = ~(size_t)0;
+  uint32_t cur = 0;
+  while (true) {
+    int code;
+    if (a.kind == KIND_SW) {
+      if (i == 0 || j == 0) break;  // border pointers are 'X' (main.cpp:1203-1204)
+    } else {
+      if (i == 0 && j == 0) break;
+    }
+    if (i == 0) {
+      code = 1;  // row 0: 'E'/'e' (main.cpp:727-728); LCS drain (main.cpp:1629-1634)
+    } else if (j == 0) {
+      code = 2;  // column 0: 'F'/'f' (main.cpp:609-616); LCS drain (main.cpp:1623-1628)
+    } else {
+      int sh;
+      const size_t idx = trace_word_index(i, j, a.K, a.W, sh);
+      if (idx != cur_idx) {
+        cur = a.trace[idx];
+        cur_idx = idx;
+      }
+      code = (cur >> sh) & 3;
+      if (code == 3) break;  // SW stop cell
+    }
+    a.ops[nops++] = (uint8_t)code;
+    if (code == 0) {
+      --i;
+      --j;
+    } else if (code == 1) {
+      --j;
+    } else {
+      --i;
+    }
+  }
+  a.hdr[0] = nops;
+  a.hdr[3] = i;
+  a.hdr[4] = j;
+}
+
+}  // namespace sa

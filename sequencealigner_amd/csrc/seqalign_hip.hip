@@ -1,0 +1,525 @@
+// seqalign_hip.hip -- host side of libseqalign_hip.so: the C-ABI declared in
+// include/seqalign_hip.h on top of the gfx950 kernels in sa_kernels.h.
+//
+// What runs where: residue validation / encoding, the two O(m+n) border chains and the
+// launch schedule are host code; the O(m*n) fill, the SW arg-max and the traceback walk
+// are device code.  There is no CPU fallback for any of the device parts.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/seqalign_hip.h"
+#include "sa_kernels.h"
+#include "sa_tables.h"
+
+using namespace sa;
+
+namespace {
+
+struct Buf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace
+
+struct sa_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::string err;
+  int force_K = 0, force_C = 0;
+  // cached device workspaces
+  Buf xenc, yenc, prof, sub, colb, bot, state, trace, rowbest, small, ops;
+  // batch workspaces
+  Buf b_seq, b_desc, b_out;
+  // pinned host staging
+  void* h_small = nullptr;
+};
+
+namespace {
+
+int fail(sa_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  return code;
+}
+
+#define HIPCK(ctx, call)                                                                            \
+  do {                                                                                              \
+    hipError_t e_ = (call);                                                                         \
+    if (e_ != hipSuccess)                                                                           \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? SA_ERR_NOMEM : SA_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
+                  hipGetErrorString(e_), __FILE__, __LINE__);                                       \
+  } while (0)
+
+int ensure(sa_ctx* ctx, Buf& b, size_t bytes) {
+  if (bytes <= b.cap) return SA_OK;
+  if (b.p) HIPCK(ctx, hipFree(b.p));
+  b.p = nullptr;
+  b.cap = 0;
+  size_t want = (bytes + 255) & ~size_t(255);
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) {
+    b.p = nullptr;
+    return fail(ctx, SA_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+  }
+  b.cap = want;
+  return SA_OK;
+}
+
+void release(Buf& b) {
+  if (b.p) (void)hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+}
+
+// int + double truncated back to int, as every "score + GAP" of the reference (main.cpp:603).
+inline int add_gap(int v, double g) { return (int)((double)v + g); }
+
+struct Tuning {
+  int K, C;
+};
+
+// Pick rows-per-lane K and tile length C by a small cost model: a wave issues one VALU
+// instruction per 4 cycles and one wave saturates its SIMD (measured, profiles/), so the time
+// is max(critical path over launches, total work / 1024 SIMDs).
+Tuning choose_tuning(const sa_ctx* ctx, int kind, int64_t m, int64_t n) {
+  const double cell = kind == KIND_LCS ? 8.0 : (kind == KIND_SW ? 19.0 : 15.0);
+  const double step0 = kind == KIND_LCS ? 9.0 : 13.0;
+  const double launch_cycles = 2.5e-6 * 2.4e9;
+  double best = 1e300;
+  Tuning t{4, 256};
+  for (int K : {1, 2, 4, 8}) {
+    for (int C : {64, 128, 256, 512}) {
+      if (ctx->force_K && K != ctx->force_K) continue;
+      if (ctx->force_C && C != ctx->force_C) continue;
+      const double S = std::ceil((double)m / (64.0 * K));
+      const double L = std::ceil((64.0 * S + n + 63) / C) + S;
+      const double tile = C * (cell * K + step0) * 4.0 + 3000.0;  // + state/profile load
+      const double crit = L * (tile + launch_cycles);
+      const double thr = S * std::ceil((n + 63.0) / C) * tile / 1024.0;
+      const double est = std::max(crit, thr) + 0.05 * std::min(crit, thr);
+      if (est < best) {
+        best = est;
+        t = {K, C};
+      }
+    }
+  }
+  if (ctx->force_K) t.K = ctx->force_K;
+  if (ctx->force_C) t.C = ctx->force_C;
+  return t;
+}
+
+template <int KIND>
+void launch_fill(int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a) {
+  switch (K) {
+    case 1: hipLaunchKernelGGL((fill_tile<KIND, 1>), grid, dim3(64), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((fill_tile<KIND, 2>), grid, dim3(64), lds, st, a); break;
+    case 4: hipLaunchKernelGGL((fill_tile<KIND, 4>), grid, dim3(64), lds, st, a); break;
+    default: hipLaunchKernelGGL((fill_tile<KIND, 8>), grid, dim3(64), lds, st, a); break;
+  }
+}
+
+void launch_profile(int K, hipStream_t st, const uint8_t* xidx, int m, const int8_t* sub, int alpha, int S,
+                    uint32_t* prof) {
+  const size_t total = (size_t)S * alpha * 64;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 65535);
+  switch (K) {
+    case 1: hipLaunchKernelGGL(build_profile<1>, dim3(blocks), dim3(256), 0, st, xidx, m, sub, alpha, S, prof); break;
+    case 2: hipLaunchKernelGGL(build_profile<2>, dim3(blocks), dim3(256), 0, st, xidx, m, sub, alpha, S, prof); break;
+    case 4: hipLaunchKernelGGL(build_profile<4>, dim3(blocks), dim3(256), 0, st, xidx, m, sub, alpha, S, prof); break;
+    default: hipLaunchKernelGGL(build_profile<8>, dim3(blocks), dim3(256), 0, st, xidx, m, sub, alpha, S, prof); break;
+  }
+}
+
+// The pair the reference's score function would throw on first, scanning cells in its
+// row-major fill order (main.cpp:640 inside :622, :738): returns false if every cell is valid.
+bool first_invalid_pair(const uint8_t* x, int64_t m, const uint8_t* y, int64_t n, const uint8_t* map,
+                        unsigned char* bx, unsigned char* by) {
+  if (m == 0 || n == 0) return false;
+  int64_t jbad = -1;
+  for (int64_t j = 0; j < n; ++j)
+    if (map[y[j]] == 255) {
+      jbad = j;
+      break;
+    }
+  for (int64_t i = 0; i < m; ++i) {
+    if (map[x[i]] == 255) {
+      *bx = x[i];
+      *by = y[0];
+      return true;
+    }
+    if (jbad >= 0) {
+      *bx = x[i];
+      *by = y[jbad];
+      return true;
+    }
+  }
+  return false;
+}
+
+// Degenerate shapes never reach the GPU: with m==0 or n==0 there is no cell to fill and the
+// reference's traceback only walks a border (main.cpp:796-806, 1623-1634).
+void border_only_result(int kind, int64_t m, int64_t n, const std::vector<int>& rowb, const std::vector<int>& colb,
+                        sa_result* out) {
+  out->end_i = (kind == KIND_SW) ? 0 : m;
+  out->end_j = (kind == KIND_SW) ? 0 : n;
+  out->start_i = out->start_j = 0;
+  out->score = 0;
+  if (kind == KIND_SW) return;
+  if (kind == KIND_NW) out->score = (m == 0) ? rowb[n] : colb[m];
+  const int64_t len = m + n;
+  if (len > 0) {
+    out->ops = (uint8_t*)malloc((size_t)len);
+    memset(out->ops, m == 0 ? 1 : 2, (size_t)len);
+    out->n_ops = len;
+  }
+}
+
+int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t* y, int64_t n64,
+             const sa_scoring* sc, uint32_t flags, sa_result* out) {
+  if (!ctx) return SA_ERR_ARG;
+  if (!out) return fail(ctx, SA_ERR_ARG, "out is NULL");
+  memset(out, 0, sizeof *out);
+  if (m64 < 0 || n64 < 0 || (m64 > 0 && !x) || (n64 > 0 && !y)) return fail(ctx, SA_ERR_ARG, "bad sequence arguments");
+  if (m64 > 0x7ff00000LL || n64 > 0x7ff00000LL) return fail(ctx, SA_ERR_ARG, "sequence longer than int32 indexing (reference Q7)");
+  if (flags & SA_FLAG_KEEP_DP) return fail(ctx, SA_ERR_UNSUPPORTED, "SA_FLAG_KEEP_DP is not implemented yet");
+  const int m = (int)m64, n = (int)n64;
+  int go = 0, ge = 0, alpha = 1;
+  if (kind != KIND_LCS) {
+    if (!sc || !sc->sub || !sc->idx256 || sc->alpha < 1 || sc->alpha > 32) return fail(ctx, SA_ERR_ARG, "bad scoring");
+    if (sc->gap_open != std::floor(sc->gap_open) || sc->gap_extend != std::floor(sc->gap_extend))
+      return fail(ctx, SA_ERR_UNSUPPORTED,
+                  "fractional gap penalties (%g, %g) need the reference's per-op truncation; not implemented on the GPU path yet",
+                  sc->gap_open, sc->gap_extend);
+    if (std::fabs(sc->gap_open) > 1e6 || std::fabs(sc->gap_extend) > 1e6) return fail(ctx, SA_ERR_ARG, "gap penalty out of range");
+    go = (int)sc->gap_open;
+    ge = (int)sc->gap_extend;
+    alpha = sc->alpha;
+    const double worst = ((double)m + n + 2) * std::max({std::fabs((double)go), std::fabs((double)ge), 128.0});
+    if (worst > 1.0e9) return fail(ctx, SA_ERR_ARG, "score range would overflow int32");
+    if (first_invalid_pair(x, m, y, n, sc->idx256, &out->bad_x, &out->bad_y))
+      return fail(ctx, SA_ERR_INVALID_CODE, "invalid residue pair %c,%c", out->bad_x, out->bad_y);
+  }
+
+  // border chains, literally as the reference builds them (host, O(m+n))
+  std::vector<int> rowb((size_t)n + 1, 0), colb((size_t)m + 1, 0);
+  if (kind == KIND_NW) {
+    for (int j = 1; j <= n; ++j) rowb[j] = (j == 1) ? add_gap(rowb[0], sc->gap_open) : add_gap(rowb[j - 1], sc->gap_extend);  // main.cpp:719-725
+    int fprev = kNeg;
+    for (int i = 1; i <= m; ++i) {  // main.cpp:601-606
+      const int fo = add_gap(colb[i - 1], sc->gap_open), fe = add_gap(fprev, sc->gap_extend);
+      fprev = std::max(fo, fe);
+      colb[i] = fprev;
+    }
+  }
+  if (m == 0 || n == 0) {
+    border_only_result(kind, m, n, rowb, colb, out);
+    return SA_OK;
+  }
+
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const Tuning tun = choose_tuning(ctx, kind, m, n);
+  const int K = tun.K, C = tun.C;
+  const int PW = (K <= 4) ? 1 : K / 4;
+  const int S = (m + 64 * K - 1) / (64 * K);
+  const int Tend = ((n + 63 + 63) / 64) * 64;
+  const int W = Tend / 16;
+  const int NP = Tend + 256;
+  const int NF = (kind == KIND_LCS) ? K + 3 : (kind == KIND_SW ? 4 * K + 4 : 2 * K + 4);
+  const size_t rows_pad = (size_t)S * 64 * K;
+  out->rows_per_lane = K;
+  out->tile_steps = C;
+
+  int rc;
+  if ((rc = ensure(ctx, ctx->xenc, rows_pad + 64))) return rc;
+  if ((rc = ensure(ctx, ctx->yenc, (size_t)Tend + 256))) return rc;
+  if ((rc = ensure(ctx, ctx->colb, (rows_pad + 1) * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->bot, (size_t)4 * NP * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->state, (size_t)S * NF * 64 * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->small, 256))) return rc;
+  if ((rc = ensure(ctx, ctx->ops, (size_t)m + n + 64))) return rc;
+  if (kind != KIND_LCS) {
+    if ((rc = ensure(ctx, ctx->prof, (size_t)S * alpha * 64 * PW * 4))) return rc;
+    if ((rc = ensure(ctx, ctx->sub, 32 * 32))) return rc;
+  }
+  if (kind == KIND_SW && (rc = ensure(ctx, ctx->rowbest, (size_t)2 * m * 4))) return rc;
+  const size_t trace_bytes = (size_t)S * W * 64 * K * 4;
+  if ((rc = ensure(ctx, ctx->trace, trace_bytes))) return rc;
+
+  // host-side encoding (O(m+n))
+  std::vector<uint8_t> xe(rows_pad + 64, 0), ye((size_t)Tend + 256, 0);
+  if (kind == KIND_LCS) {
+    memcpy(xe.data(), x, (size_t)m);
+    memcpy(ye.data(), y, (size_t)n);
+  } else {
+    for (int i = 0; i < m; ++i) xe[i] = sc->idx256[x[i]];
+    for (int j = 0; j < n; ++j) ye[j] = sc->idx256[y[j]];
+  }
+  std::vector<int> colpad(rows_pad + 1, 0);
+  memcpy(colpad.data(), colb.data(), ((size_t)m + 1) * 4);
+  for (size_t i = (size_t)m + 1; i <= rows_pad; ++i) colpad[i] = colb[m];
+
+  HIPCK(ctx, hipEventRecord(ctx->ev[0], st));
+  HIPCK(ctx, hipMemcpyAsync(ctx->xenc.p, xe.data(), xe.size(), hipMemcpyHostToDevice, st));
+  HIPCK(ctx, hipMemcpyAsync(ctx->yenc.p, ye.data(), ye.size(), hipMemcpyHostToDevice, st));
+  HIPCK(ctx, hipMemcpyAsync(ctx->colb.p, colpad.data(), colpad.size() * 4, hipMemcpyHostToDevice, st));
+  int* botH = (int*)ctx->bot.p;
+  int* botF = botH + (size_t)2 * NP;
+  // strip 0 reads ring buffer 1: row 0 of the matrix, H[0][j] at p = j + 63
+  HIPCK(ctx, hipMemsetAsync(botH, 0, (size_t)2 * NP * 4, st));
+  HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)botF, kind == KIND_NW ? kNeg : 0, (size_t)2 * NP, st));
+  if (kind == KIND_NW) HIPCK(ctx, hipMemcpyAsync(botH + NP + 64, rowb.data() + 1, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  HIPCK(ctx, hipMemsetAsync(ctx->small.p, 0, 256, st));
+  int* d_score = (int*)ctx->small.p;                                         // [0]   NW/LCS score / SW best
+  unsigned long long* d_pos = (unsigned long long*)((char*)ctx->small.p + 8);  // [8]   SW end cell
+  long long* d_hdr = (long long*)((char*)ctx->small.p + 64);                 // [64]  traceback header
+  if (kind == KIND_SW) HIPCK(ctx, hipMemsetAsync(d_pos, 0xff, 8, st));
+  if (kind != KIND_LCS) {
+    HIPCK(ctx, hipMemcpyAsync(ctx->sub.p, sc->sub, (size_t)alpha * alpha, hipMemcpyHostToDevice, st));
+    launch_profile(K, st, (const uint8_t*)ctx->xenc.p, m, (const int8_t*)ctx->sub.p, alpha, S, (uint32_t*)ctx->prof.p);
+  }
+
+  FillArgs a{};
+  a.m = m;
+  a.n = n;
+  a.S = S;
+  a.C = C;
+  a.W = W;
+  a.go = go;
+  a.ge = ge;
+  a.alpha = alpha;
+  a.NP = NP;
+  a.yenc = (const uint8_t*)ctx->yenc.p;
+  a.prof = (const uint32_t*)ctx->prof.p;
+  a.xpad = (const uint8_t*)ctx->xenc.p;
+  a.colb = (const int*)ctx->colb.p;
+  a.botH = botH;
+  a.botF = botF;
+  a.state = (int*)ctx->state.p;
+  a.trace = (uint32_t*)ctx->trace.p;
+  a.rowbest = (int*)ctx->rowbest.p;
+  a.rowbestc = a.rowbest ? a.rowbest + m : nullptr;
+  a.score_out = d_score;
+
+  const size_t lds = (kind == KIND_LCS) ? 0 : (size_t)alpha * 64 * PW * 4;
+  auto f_lo = [&](int s) { return (long long)s + (64LL * s) / C; };
+  auto f_hi = [&](int s) { return (long long)s + (64LL * s + n + 62) / C; };
+  const long long dmax = f_hi(S - 1);
+  int slo = 0, shi = -1, launches = 0;
+  HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
+  for (long long d = 0; d <= dmax; ++d) {
+    while (shi + 1 < S && f_lo(shi + 1) <= d) ++shi;
+    while (slo < S && f_hi(slo) < d) ++slo;
+    if (slo > shi) continue;
+    a.d = (int)d;
+    a.s_lo = slo;
+    const dim3 grid(shi - slo + 1);
+    if (kind == KIND_NW)
+      launch_fill<KIND_NW>(K, grid, lds, st, a);
+    else if (kind == KIND_SW)
+      launch_fill<KIND_SW>(K, grid, lds, st, a);
+    else
+      launch_fill<KIND_LCS>(K, grid, lds, st, a);
+    ++launches;
+  }
+  HIPCK(ctx, hipGetLastError());
+  out->n_launches = launches;
+  if (kind == KIND_SW) {
+    const int rb = std::min((m + 255) / 256, 1024);
+    hipLaunchKernelGGL(sw_reduce_max, dim3(rb), dim3(256), 0, st, a.rowbest, m, d_score);
+    hipLaunchKernelGGL(sw_reduce_pos, dim3(rb), dim3(256), 0, st, a.rowbest, a.rowbestc, m, d_score, d_pos);
+  }
+  HIPCK(ctx, hipEventRecord(ctx->ev[2], st));
+
+  struct {
+    int score;
+    int pad;
+    unsigned long long pos;
+  } h_sc{};
+  long long h_hdr[5] = {0, 0, 0, 0, 0};
+  const bool want_tb = !(flags & SA_FLAG_NO_TRACEBACK);
+  if (want_tb) {
+    TraceArgs t{};
+    t.kind = kind;
+    t.m = m;
+    t.n = n;
+    t.K = K;
+    t.W = W;
+    t.trace = a.trace;
+    t.sw_best = d_score;
+    t.sw_pos = d_pos;
+    t.ops = (uint8_t*)ctx->ops.p;
+    t.hdr = d_hdr;
+    hipLaunchKernelGGL(traceback_walk, dim3(1), dim3(64), 0, st, t);
+    HIPCK(ctx, hipGetLastError());
+    HIPCK(ctx, hipMemcpyAsync(h_hdr, d_hdr, sizeof h_hdr, hipMemcpyDeviceToHost, st));
+  }
+  HIPCK(ctx, hipMemcpyAsync(&h_sc, ctx->small.p, 16, hipMemcpyDeviceToHost, st));
+  HIPCK(ctx, hipStreamSynchronize(st));
+  if (want_tb && h_hdr[0] > 0) {
+    out->ops = (uint8_t*)malloc((size_t)h_hdr[0]);
+    if (!out->ops) return fail(ctx, SA_ERR_NOMEM, "host malloc of %lld ops failed", h_hdr[0]);
+    HIPCK(ctx, hipMemcpyAsync(out->ops, ctx->ops.p, (size_t)h_hdr[0], hipMemcpyDeviceToHost, st));
+  }
+  HIPCK(ctx, hipEventRecord(ctx->ev[3], st));
+  HIPCK(ctx, hipEventSynchronize(ctx->ev[3]));
+  float t01 = 0, t12 = 0, t23 = 0;
+  HIPCK(ctx, hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]));
+  HIPCK(ctx, hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]));
+  HIPCK(ctx, hipEventElapsedTime(&t23, ctx->ev[2], ctx->ev[3]));
+  out->fill_ms = t01 + t12;
+  out->kernel_fill_ms = t12;
+  out->traceback_ms = t23;
+
+  out->score = h_sc.score;
+  if (kind == KIND_SW) {
+    if (h_sc.score > 0) {
+      out->end_i = (int64_t)(h_sc.pos >> 32);
+      out->end_j = (int64_t)(h_sc.pos & 0xffffffffu);
+    }
+    out->start_i = out->end_i;
+    out->start_j = out->end_j;
+  } else {
+    out->end_i = m;
+    out->end_j = n;
+  }
+  if (want_tb) {
+    out->n_ops = h_hdr[0];
+    out->start_i = h_hdr[3];
+    out->start_j = h_hdr[4];
+  }
+  return SA_OK;
+}
+
+struct Builtin {
+  int8_t sub[2][32 * 32];
+  uint8_t map[2][256];
+  sa_scoring sc[2];
+  Builtin() {
+    sa_tables::parse_table(sa_tables::kNuc44Text, 15, sub[0]);
+    sa_tables::parse_table(sa_tables::kBlosum62Text, 24, sub[1]);
+    sa_tables::dna_idx256(map[0]);
+    sa_tables::prot_idx256(map[1]);
+    sc[0] = sa_scoring{-5.0, -1.0, sub[0], 15, map[0]};
+    sc[1] = sa_scoring{-5.0, -1.0, sub[1], 24, map[1]};
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+sa_ctx* sa_create(int device_id) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return nullptr;
+  if (hipSetDevice(device_id) != hipSuccess) return nullptr;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return nullptr;
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    fprintf(stderr, "seqalign_hip: device %d is %s; this library carries gfx950 code only\n", device_id, prop.gcnArchName);
+    return nullptr;
+  }
+  sa_ctx* c = new sa_ctx;
+  c->device = device_id;
+  if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
+    delete c;
+    return nullptr;
+  }
+  c->stream = c->own_stream;
+  for (auto& e : c->ev)
+    if (hipEventCreate(&e) != hipSuccess) {
+      delete c;
+      return nullptr;
+    }
+  return c;
+}
+
+void sa_destroy(sa_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  sa_release_workspace(c);
+  for (auto& e : c->ev)
+    if (e) (void)hipEventDestroy(e);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+const char* sa_last_error(const sa_ctx* c) { return c ? c->err.c_str() : "null context"; }
+
+int sa_set_stream(sa_ctx* c, void* s) {
+  if (!c) return SA_ERR_ARG;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return SA_OK;
+}
+
+int sa_set_tuning(sa_ctx* c, int K, int C) {
+  if (!c) return SA_ERR_ARG;
+  if (!(K == 0 || K == 1 || K == 2 || K == 4 || K == 8)) return fail(c, SA_ERR_ARG, "rows_per_lane must be 0,1,2,4,8");
+  if (C < 0 || C % 64 != 0 || C > 4096) return fail(c, SA_ERR_ARG, "tile_steps must be a multiple of 64 (<=4096)");
+  c->force_K = K;
+  c->force_C = C;
+  return SA_OK;
+}
+
+int sa_release_workspace(sa_ctx* c) {
+  if (!c) return SA_ERR_ARG;
+  (void)hipSetDevice(c->device);
+  for (Buf* b : {&c->xenc, &c->yenc, &c->prof, &c->sub, &c->colb, &c->bot, &c->state, &c->trace, &c->rowbest, &c->small,
+                 &c->ops, &c->b_seq, &c->b_desc, &c->b_out})
+    release(*b);
+  return SA_OK;
+}
+
+void sa_free_result(sa_result* r) {
+  if (!r) return;
+  free(r->ops);
+  free(r->dp);
+  r->ops = nullptr;
+  r->dp = nullptr;
+  r->n_ops = 0;
+}
+
+const sa_scoring* sa_builtin_scoring(int mode) {
+  static const Builtin b;
+  if (mode == SA_MODE_DNA) return &b.sc[0];
+  if (mode == SA_MODE_PROTEIN) return &b.sc[1];
+  return nullptr;
+}
+
+int sa_nw(sa_ctx* ctx, const uint8_t* x, int64_t m, const uint8_t* y, int64_t n, const sa_scoring* sc, uint32_t flags,
+          sa_result* out) {
+  return run_pair(ctx, KIND_NW, x, m, y, n, sc, flags, out);
+}
+
+int sa_sw(sa_ctx* ctx, const uint8_t* x, int64_t m, const uint8_t* y, int64_t n, const sa_scoring* sc, uint32_t flags,
+          sa_result* out) {
+  return run_pair(ctx, KIND_SW, x, m, y, n, sc, flags, out);
+}
+
+int sa_lcs(sa_ctx* ctx, const uint8_t* x, int64_t m, const uint8_t* y, int64_t n, uint32_t flags, sa_result* out) {
+  return run_pair(ctx, KIND_LCS, x, m, y, n, nullptr, flags, out);
+}
+
+int sa_sw_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x, const int64_t* off_y,
+                const int32_t* len_y, int64_t n_pairs, const sa_scoring* sc, int32_t* score, int32_t* end_i,
+                int32_t* end_j, float* kernel_ms) {
+  (void)seqs; (void)off_x; (void)len_x; (void)off_y; (void)len_y; (void)n_pairs; (void)sc; (void)score; (void)end_i; (void)end_j; (void)kernel_ms;
+  return fail(ctx, SA_ERR_UNSUPPORTED, "sa_sw_batch: not implemented yet");
+}
+
+}  // extern "C"

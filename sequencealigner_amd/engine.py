@@ -1,0 +1,260 @@
+"""ctypes binding of include/seqalign_hip.h.
+
+Function names mirror the reference's hot-path entry points (src/main.cpp):
+  globalalign(x, y, mode, gap_open, gap_extend)  <- globalalign(), main.cpp:691
+  localalign(...)                                <- localalign(),  main.cpp:1037
+  lcs(x, y)                                      <- lcs(),         main.cpp:1562
+Each returns an AlignResult (score, end/start cell, traceback ops) instead of writing
+files; the C++ CLI (csrc/aligner_main.cpp) owns the byte-exact writers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from pathlib import Path
+from typing import Optional
+
+import numpy as np
+
+_PKG = Path(__file__).resolve().parent
+_LIB_NAME = "libseqalign_hip.so"
+
+SA_OK = 0
+SA_ERR_INVALID_CODE = -2
+SA_ERR_NOMEM = -3
+SA_ERR_HIP = -4
+SA_ERR_ARG = -5
+SA_ERR_UNSUPPORTED = -6
+SA_FLAG_KEEP_DP = 1
+SA_FLAG_NO_TRACEBACK = 2
+MODES = {"dna": 0, "protein": 1}
+
+
+class SeqAlignError(RuntimeError):
+    def __init__(self, code, msg, bad=None):
+        super().__init__(msg)
+        self.code = code
+        self.bad = bad
+
+
+class _Scoring(C.Structure):
+    _fields_ = [
+        ("gap_open", C.c_double),
+        ("gap_extend", C.c_double),
+        ("sub", C.c_void_p),
+        ("alpha", C.c_int32),
+        ("idx256", C.c_void_p),
+    ]
+
+
+class _Result(C.Structure):
+    _fields_ = [
+        ("score", C.c_int64),
+        ("end_i", C.c_int64),
+        ("end_j", C.c_int64),
+        ("start_i", C.c_int64),
+        ("start_j", C.c_int64),
+        ("ops", C.POINTER(C.c_uint8)),
+        ("n_ops", C.c_int64),
+        ("dp", C.POINTER(C.c_int32)),
+        ("bad_x", C.c_ubyte),
+        ("bad_y", C.c_ubyte),
+        ("fill_ms", C.c_float),
+        ("traceback_ms", C.c_float),
+        ("kernel_fill_ms", C.c_float),
+        ("n_launches", C.c_int32),
+        ("rows_per_lane", C.c_int32),
+        ("tile_steps", C.c_int32),
+    ]
+
+
+@dataclass
+class AlignResult:
+    score: int
+    end: tuple
+    start: tuple
+    ops: np.ndarray
+    dp: Optional[np.ndarray] = None
+    fill_ms: float = 0.0
+    traceback_ms: float = 0.0
+    kernel_fill_ms: float = 0.0
+    n_launches: int = 0
+    rows_per_lane: int = 0
+    tile_steps: int = 0
+    extra: dict = field(default_factory=dict)
+
+
+def lib_path() -> Path:
+    return _PKG / _LIB_NAME
+
+
+_lib = None
+
+
+def load_library() -> C.CDLL:
+    """Load libseqalign_hip.so from the package directory.  No fallback: a missing
+    library is an error (build it with `python -c 'import __graft_entry__ as g; g.build()'`
+    or `make -C sequencealigner_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    p = lib_path()
+    if not p.exists():
+        raise SeqAlignError(SA_ERR_HIP, f"{p} is missing: the HIP extension was not built; there is no CPU fallback")
+    L = C.CDLL(str(p))
+    vp = C.c_void_p
+    L.sa_create.argtypes = [C.c_int]
+    L.sa_create.restype = vp
+    L.sa_destroy.argtypes = [vp]
+    L.sa_destroy.restype = None
+    L.sa_last_error.argtypes = [vp]
+    L.sa_last_error.restype = C.c_char_p
+    L.sa_set_stream.argtypes = [vp, vp]
+    L.sa_set_tuning.argtypes = [vp, C.c_int, C.c_int]
+    L.sa_release_workspace.argtypes = [vp]
+    L.sa_free_result.argtypes = [C.POINTER(_Result)]
+    L.sa_free_result.restype = None
+    L.sa_builtin_scoring.argtypes = [C.c_int]
+    L.sa_builtin_scoring.restype = C.POINTER(_Scoring)
+    pair = [vp, vp, C.c_int64, vp, C.c_int64, C.POINTER(_Scoring), C.c_uint32, C.POINTER(_Result)]
+    L.sa_nw.argtypes = pair
+    L.sa_sw.argtypes = pair
+    L.sa_lcs.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_uint32, C.POINTER(_Result)]
+    L.sa_sw_batch.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, C.POINTER(_Scoring), vp, vp, vp, C.POINTER(C.c_float)]
+    for f in ("sa_set_stream", "sa_set_tuning", "sa_release_workspace", "sa_nw", "sa_sw", "sa_lcs", "sa_sw_batch"):
+        getattr(L, f).restype = C.c_int
+    _lib = L
+    return L
+
+
+def _u8(b) -> np.ndarray:
+    if isinstance(b, str):
+        b = b.encode("latin-1")
+    if isinstance(b, (bytes, bytearray)):
+        return np.frombuffer(bytes(b), dtype=np.uint8)
+    return np.ascontiguousarray(b, dtype=np.uint8)
+
+
+class Engine:
+    """One sa_ctx on one GPU."""
+
+    def __init__(self, device: int = 0):
+        self.lib = load_library()
+        self.ctx = self.lib.sa_create(device)
+        if not self.ctx:
+            raise SeqAlignError(SA_ERR_HIP, f"sa_create({device}) failed: no gfx950 GPU visible; there is no CPU fallback")
+
+    def close(self):
+        if getattr(self, "ctx", None):
+            self.lib.sa_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers -----------------------------------------------------------
+    def _scoring(self, mode, gap_open, gap_extend, sub=None, idx256=None):
+        base = self.lib.sa_builtin_scoring(MODES[mode]).contents
+        sc = _Scoring(float(gap_open), float(gap_extend), base.sub, base.alpha, base.idx256)
+        keep = []
+        if sub is not None:
+            sub = np.ascontiguousarray(sub, np.int8)
+            idx256 = np.ascontiguousarray(idx256, np.uint8)
+            sc.sub, sc.alpha, sc.idx256 = sub.ctypes.data, sub.shape[0], idx256.ctypes.data
+            keep = [sub, idx256]
+        return sc, keep
+
+    def _err(self, rc, r):
+        msg = self.lib.sa_last_error(self.ctx).decode()
+        bad = (chr(r.bad_x), chr(r.bad_y)) if rc == SA_ERR_INVALID_CODE else None
+        return SeqAlignError(rc, msg, bad)
+
+    def _wrap(self, r, m, n, keep_dp) -> AlignResult:
+        ops = np.ctypeslib.as_array(r.ops, shape=(r.n_ops,)).copy() if r.n_ops else np.zeros(0, np.uint8)
+        dp = None
+        if keep_dp and r.dp:
+            dp = np.ctypeslib.as_array(r.dp, shape=(m + 1, n + 1)).copy()
+        out = AlignResult(int(r.score), (int(r.end_i), int(r.end_j)), (int(r.start_i), int(r.start_j)), ops, dp,
+                          r.fill_ms, r.traceback_ms, r.kernel_fill_ms, r.n_launches, r.rows_per_lane, r.tile_steps)
+        self.lib.sa_free_result(C.byref(r))
+        return out
+
+    def set_tuning(self, rows_per_lane=0, tile_steps=0):
+        rc = self.lib.sa_set_tuning(self.ctx, rows_per_lane, tile_steps)
+        if rc:
+            raise SeqAlignError(rc, self.lib.sa_last_error(self.ctx).decode())
+
+    def set_stream(self, stream_handle):
+        self.lib.sa_set_stream(self.ctx, stream_handle)
+
+    def release_workspace(self):
+        self.lib.sa_release_workspace(self.ctx)
+
+    # ---- hot path -------------------------------------------------------------
+    def _pair(self, fn, x, y, mode, gap_open, gap_extend, flags, sub=None, idx256=None):
+        x, y = _u8(x), _u8(y)
+        sc, keep = self._scoring(mode, gap_open, gap_extend, sub, idx256)
+        r = _Result()
+        rc = fn(self.ctx, x.ctypes.data, len(x), y.ctypes.data, len(y), C.byref(sc), flags, C.byref(r))
+        del keep
+        if rc:
+            raise self._err(rc, r)
+        return self._wrap(r, len(x), len(y), bool(flags & SA_FLAG_KEEP_DP))
+
+    def nw(self, x, y, mode="dna", gap_open=-5.0, gap_extend=-1.0, flags=0, **kw) -> AlignResult:
+        return self._pair(self.lib.sa_nw, x, y, mode, gap_open, gap_extend, flags, **kw)
+
+    def sw(self, x, y, mode="dna", gap_open=-5.0, gap_extend=-1.0, flags=0, **kw) -> AlignResult:
+        return self._pair(self.lib.sa_sw, x, y, mode, gap_open, gap_extend, flags, **kw)
+
+    def lcs(self, x, y, flags=0) -> AlignResult:
+        x, y = _u8(x), _u8(y)
+        r = _Result()
+        rc = self.lib.sa_lcs(self.ctx, x.ctypes.data, len(x), y.ctypes.data, len(y), flags, C.byref(r))
+        if rc:
+            raise self._err(rc, r)
+        return self._wrap(r, len(x), len(y), bool(flags & SA_FLAG_KEEP_DP))
+
+    def sw_batch(self, seqs, off_x, len_x, off_y, len_y, mode="protein", gap_open=-5.0, gap_extend=-1.0):
+        seqs = _u8(seqs)
+        off_x = np.ascontiguousarray(off_x, np.int64)
+        off_y = np.ascontiguousarray(off_y, np.int64)
+        len_x = np.ascontiguousarray(len_x, np.int32)
+        len_y = np.ascontiguousarray(len_y, np.int32)
+        n = len(off_x)
+        score = np.zeros(n, np.int32)
+        ei = np.zeros(n, np.int32)
+        ej = np.zeros(n, np.int32)
+        sc, keep = self._scoring(mode, gap_open, gap_extend)
+        ms = C.c_float(0)
+        rc = self.lib.sa_sw_batch(self.ctx, seqs.ctypes.data, off_x.ctypes.data, len_x.ctypes.data, off_y.ctypes.data,
+                                  len_y.ctypes.data, n, C.byref(sc), score.ctypes.data, ei.ctypes.data, ej.ctypes.data,
+                                  C.byref(ms))
+        if rc and rc != SA_ERR_INVALID_CODE:
+            raise SeqAlignError(rc, self.lib.sa_last_error(self.ctx).decode())
+        return score, ei, ej, ms.value, rc
+
+
+_default: Optional[Engine] = None
+
+
+def _engine() -> Engine:
+    global _default
+    if _default is None:
+        _default = Engine(0)
+    return _default
+
+
+def globalalign(x, y, mode="dna", gap_open=-5.0, gap_extend=-1.0) -> AlignResult:
+    return _engine().nw(x, y, mode, gap_open, gap_extend)
+
+
+def localalign(x, y, mode="dna", gap_open=-5.0, gap_extend=-1.0) -> AlignResult:
+    return _engine().sw(x, y, mode, gap_open, gap_extend)
+
+
+def lcs(x, y) -> AlignResult:
+    return _engine().lcs(x, y)

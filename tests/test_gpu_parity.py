@@ -1,0 +1,139 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle, bit-exact
+(integer DP: score, end/start cell and the complete traceback op list)."""
+import numpy as np
+import pytest
+
+from conftest import DNA, IUPAC, PROT20, PROT24, mutate, rand_seq
+
+pytestmark = pytest.mark.gpu
+
+
+def check(kind, eng, orc, x, y, mode="dna", go=-5.0, ge=-1.0):
+    if kind == "nw":
+        g = eng.nw(x, y, mode, go, ge)
+        o = orc.nw(x, y, mode, go, ge)
+    elif kind == "sw":
+        g = eng.sw(x, y, mode, go, ge)
+        o = orc.sw(x, y, mode, go, ge)
+    else:
+        g = eng.lcs(x, y)
+        o = orc.lcs(x, y)
+    assert o.rc == 0
+    ctx = f"{kind} m={len(x)} n={len(y)} mode={mode} go={go} ge={ge} K={g.rows_per_lane} C={g.tile_steps}"
+    assert g.score == o.score, ctx
+    assert g.end == o.end, ctx
+    assert g.start == o.start, ctx
+    assert len(g.ops) == len(o.ops), ctx
+    assert np.array_equal(g.ops, o.ops), ctx
+    return g
+
+
+SHAPES = [(1, 1), (1, 7), (7, 1), (2, 3), (63, 64), (64, 63), (65, 65), (100, 257), (257, 100), (300, 1000),
+          (513, 129), (1000, 64), (1210, 1390), (2049, 777)]
+
+
+@pytest.mark.parametrize("kind", ["nw", "sw", "lcs"])
+@pytest.mark.parametrize("K", [1, 2, 4, 8])
+def test_random_dna_all_tilings(engine, oracle, kind, K):
+    rng = np.random.default_rng(100 + K)
+    for C in (64, 128, 256):
+        engine.set_tuning(K, C)
+        for (m, n) in SHAPES:
+            x = rand_seq(rng, m, DNA)
+            y = rand_seq(rng, n, DNA)
+            check(kind, engine, oracle, x, y, "dna")
+    engine.set_tuning(0, 0)
+
+
+@pytest.mark.parametrize("kind", ["nw", "sw", "lcs"])
+def test_similar_pairs_auto_tuning(engine, oracle, kind):
+    rng = np.random.default_rng(7)
+    engine.set_tuning(0, 0)
+    for m in (500, 3000, 6000):
+        x = rand_seq(rng, m, DNA)
+        y = mutate(rng, x, DNA)
+        check(kind, engine, oracle, x, y, "dna")
+
+
+@pytest.mark.parametrize("kind", ["nw", "sw"])
+def test_protein_full_alphabet(engine, oracle, kind):
+    rng = np.random.default_rng(11)
+    for K in (1, 4, 8):
+        engine.set_tuning(K, 128)
+        for (m, n) in [(110, 116), (443, 400), (1000, 300), (777, 1555)]:
+            x = rand_seq(rng, m, PROT24)
+            y = rand_seq(rng, n, PROT24)
+            check(kind, engine, oracle, x, y, "protein")
+            y2 = mutate(rng, x, PROT20, 0.2, 0.05, 0.05)
+            check(kind, engine, oracle, x, y2, "protein")
+    engine.set_tuning(0, 0)
+
+
+@pytest.mark.parametrize("kind", ["nw", "sw"])
+def test_iupac_dna_index_quirk(engine, oracle, kind):
+    """Quirk Q1: NUC.4.4 rows are indexed with char2idx's different order."""
+    rng = np.random.default_rng(13)
+    for (m, n) in [(19, 19), (200, 333), (1500, 900)]:
+        x = rand_seq(rng, m, IUPAC)
+        y = rand_seq(rng, n, IUPAC)
+        check(kind, engine, oracle, x, y, "dna")
+
+
+@pytest.mark.parametrize("kind", ["nw", "sw", "lcs"])
+def test_tie_storms(engine, oracle, kind):
+    """Low-complexity inputs where every comparison ties: tie-breaks must survive the
+    anti-diagonal evaluation order."""
+    cases = [("A" * 300, "A" * 257), ("AC" * 200, "CA" * 180), ("ACGT" * 100, "ACGT" * 90 + "TTTT"),
+             ("A" * 500, "T" * 400), ("AAAAAAAAAC" * 40, "AAAAAAAAAG" * 35), ("GATTACA" * 64, "GATACA" * 70)]
+    for K in (1, 2, 8):
+        engine.set_tuning(K, 64)
+        for x, y in cases:
+            check(kind, engine, oracle, x, y, "dna")
+    engine.set_tuning(0, 0)
+
+
+@pytest.mark.parametrize("go,ge", [(-10.0, -1.0), (-2.0, -2.0), (-1.0, -3.0), (0.0, 0.0), (-11.0, -1.0), (-3.0, 0.0)])
+@pytest.mark.parametrize("kind", ["nw", "sw"])
+def test_integral_gap_settings(engine, oracle, kind, go, ge):
+    rng = np.random.default_rng(17)
+    x = rand_seq(rng, 700, DNA)
+    y = mutate(rng, x, DNA, 0.1, 0.05, 0.05)
+    check(kind, engine, oracle, x, y, "dna", go, ge)
+    xp = rand_seq(rng, 333, PROT20)
+    yp = mutate(rng, xp, PROT20, 0.3, 0.05, 0.05)
+    check(kind, engine, oracle, xp, yp, "protein", go, ge)
+
+
+@pytest.mark.parametrize("kind", ["nw", "sw", "lcs"])
+def test_empty_and_tiny(engine, oracle, kind):
+    for x, y in [("", "ACGTACGT"), ("ACGTACGT", ""), ("", ""), ("A", "A"), ("A", "C"), ("AC", "A")]:
+        check(kind, engine, oracle, x, y, "dna")
+
+
+def test_invalid_residue_reports_reference_pair(engine, oracle):
+    import sequencealigner_amd as sa
+
+    for x, y in [("acgtACGT", "ACGTACGT"), ("ACGT", "ACzT"), ("ACGJ", "ACGT"), ("AJGT", "AqGT")]:
+        o = oracle.nw(x, y, "dna")
+        assert o.rc == -2
+        with pytest.raises(sa.SeqAlignError) as ei:
+            engine.nw(x, y, "dna")
+        assert ei.value.code == sa.engine.SA_ERR_INVALID_CODE
+        assert (ord(ei.value.bad[0]), ord(ei.value.bad[1])) == o.bad
+    # LCS accepts any byte (raw equality, main.cpp:1577)
+    g = engine.lcs("acgtNNxx", "acgNNtxx")
+    o = oracle.lcs("acgtNNxx", "acgNNtxx")
+    assert g.score == o.score and np.array_equal(g.ops, o.ops)
+
+
+def test_medium_dna_20k(engine, oracle):
+    rng = np.random.default_rng(23)
+    x = rand_seq(rng, 20000, DNA)
+    y = mutate(rng, x, DNA)
+    engine.set_tuning(0, 0)
+    o = oracle.nw(x, y, "dna", packed=True)
+    g = engine.nw(x, y, "dna")
+    assert g.score == o.score and np.array_equal(g.ops, o.ops)
+    ol = oracle.lcs(x, y, packed=True)
+    gl = engine.lcs(x, y)
+    assert gl.score == ol.score and np.array_equal(gl.ops, ol.ops)
