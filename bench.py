@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the DP alignment hot path (BASELINE.json metric).
+
+One "step" = one complete Needleman-Wunsch alignment (H2D of the two sequences, query
+profile, anti-diagonal fill with 2-bit traceback codes, traceback walk, D2H of the op list)
+of the synthetic ~90 %-identity DNA pair of SURVEY.md 8d (config 4: 1 Mb x 1 Mb; the timed
+window mirrors the reference's own time_ms window, main.cpp:736 -> :820).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--size L] [--kind nw|lcs|sw]
+
+N = 1 runs the whole matrix on one MI355X.  N > 1 (launched by torch.distributed.run, one
+rank per GPU) column-stripes the same pair over the ranks; see DESIGN.md "Multi-GPU".
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+import numpy as np
+
+# algorithmic work per cell: int32 VALU lane-ops and HBM bytes
+OPS_PER_CELL = {"nw": 12, "sw": 14, "lcs": 6}
+HBM_BYTES_PER_CELL = 0.25
+VALU_PEAK_TOPS = 39.3  # 256 CU x 64 lanes x 2.4 GHz int32 lane-ops/s (measured: profiles/probe_valu_r01.txt)
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(x, y, kind, sample):
+    """The oracle (CPU restatement of the reference loops, full-matrix memory behaviour) timed
+    on ONE host core on a bounded slice of the same pair.  One core is the reference's real
+    parallelism for one pair (globalalign/lcs are replicated, localalign is a
+    serial chain)."""
+    from oracle import Oracle
+
+    orc = Oracle()
+    xs, ys = x[:sample], y[:sample]
+    t0 = time.perf_counter()
+    if kind == "lcs":
+        r = orc.lcs(xs, ys, keep_dp=True)
+    else:
+        r = getattr(orc, kind)(xs, ys, "dna", keep_dp=True)
+    dt = time.perf_counter() - t0
+    assert r.rc == 0
+    cells = len(xs) * len(ys) * (2 if kind == "sw" else 1)
+    return {
+        "value": round(len(xs) * len(ys) / dt / 1e9, 4),
+        "unit": "GCUPS",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"{kind} fill+traceback of the first {len(xs)}x{len(ys)} residues of the same pair "
+                  f"({cells / 1e6:.0f} M cell updates, {dt:.1f} s), oracle/cpu_ref.c -O3, 5 B/cell matrices like the reference",
+    }, r
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--size", type=int, default=1_000_000, help="query length (target is the mutated copy, ~same length)")
+    ap.add_argument("--kind", default="nw", choices=["nw", "lcs", "sw"])
+    ap.add_argument("--cpu-sample", type=int, default=20000)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import torch
+
+    if world > 1:
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        dist = None
+
+    import sequencealigner_amd as sa
+    from sequencealigner_amd.synth import dna_pair
+
+    x, y = dna_pair(args.size, seed=1234)
+    m, n = len(x), len(y)
+    cells = m * n
+
+    if world > 1:
+        from sequencealigner_amd.stripes import StripedAligner
+
+        runner = StripedAligner(local_rank, rank, world, dist)
+        run = lambda: runner.align(args.kind, x, y, "dna")  # noqa: E731
+    else:
+        eng = sa.Engine(local_rank)
+        if args.kind == "lcs":
+            run = lambda: eng.lcs(x, y)  # noqa: E731
+        else:
+            run = lambda: getattr(eng, args.kind)(x, y, "dna")  # noqa: E731
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        res = run()
+    sync()
+    t0 = time.perf_counter()
+    kernel_ms = 0.0
+    tb_ms = 0.0
+    launches = 0
+    for _ in range(args.steps):
+        res = run()
+        kernel_ms += res.kernel_fill_ms
+        tb_ms += res.traceback_ms
+        launches += res.n_launches
+    sync()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    if rank == 0:
+        gcups = cells * args.steps / dt / 1e9
+        k_s = kernel_ms / 1e3
+        ops = OPS_PER_CELL[args.kind]
+        achieved = cells * args.steps * ops / k_s / 1e12 / world  # per GPU
+        line = {
+            "metric": "GCUPS NW fill+traceback (cell updates/s)" if args.kind == "nw" else f"GCUPS {args.kind} fill+traceback",
+            "value": round(gcups, 2),
+            "unit": "GCUPS",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "int32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.kind.upper()} {m}x{n} synthetic DNA (~90% identity, seed 1234), EDNAFULL, gaps -5/-1, "
+                            f"score + full traceback, bit-exact op list",
+                "rows_per_lane": res.rows_per_lane,
+                "tile_steps": res.tile_steps,
+                "parallelism": "single GPU" if world == 1 else f"column stripes x{world}",
+            },
+            "result": {"score": int(res.score), "n_ops": int(len(res.ops))},
+            "breakdown_ms_per_step": {
+                "fill_kernels": round(kernel_ms / args.steps, 3),
+                "traceback_plus_d2h": round(tb_ms / args.steps, 3),
+                "fill_kernel_launches": launches // args.steps,
+            },
+            "roofline": {
+                "bound": "valu",
+                "achieved": round(achieved, 3),
+                "peak": VALU_PEAK_TOPS,
+                "unit": "T int32 lane-ops/s",
+                "frac": round(achieved / VALU_PEAK_TOPS, 4),
+                "traffic": None,
+                "kernel": "fill_tile",
+                "ops_per_cell": ops,
+                "avg_launch_us": round(kernel_ms * 1e3 / max(launches, 1), 2),
+                "hbm": {
+                    "achieved": round(cells * args.steps * HBM_BYTES_PER_CELL / k_s / 1e9 / world, 1),
+                    "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s",
+                    "frac": round(cells * args.steps * HBM_BYTES_PER_CELL / k_s / 1e9 / world / HBM_PEAK_GBS, 4),
+                    "bytes_per_cell": HBM_BYTES_PER_CELL,
+                },
+            },
+        }
+        if not args.no_cpu and world == 1:
+            cb, _ = cpu_baseline(x, y, args.kind, min(args.cpu_sample, m, n))
+            line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

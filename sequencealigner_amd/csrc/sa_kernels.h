@@ -359,19 +359,24 @@ struct TraceArgs {
   long long* hdr;                      // out: n_ops, end_i, end_j, start_i, start_j
 };
 
-// direction code of matrix cell (i,j), 1-based, as stored by fill_tile
-__device__ __forceinline__ size_t trace_word_index(int i, int j, int K, int W, int& shift) {
+// Walker: one wavefront follows the pointers RUN by RUN.  At cell (i,j) lane d looks at the
+// three cells d steps away along the diagonal, the row and the column; the direction stored at
+// (i,j) selects one of the three ballots and count-trailing-ones gives the length of the run of
+// identical moves, which the lanes then emit as bytes in parallel.  One memory round trip per
+// run instead of one per move (the three gathers are in flight together).
+__device__ __forceinline__ uint32_t trace_code(const uint32_t* __restrict__ trace, int i, int j, int lgK, int W) {
   const int r = i - 1, c = j - 1;
-  const int g = r / K, k = r - g * K;
+  const int g = r >> lgK, k = r & ((1 << lgK) - 1);
   const int s = g >> 6, l = g & 63;
   const int t = c + l;
-  shift = 2 * (t & 15);
-  return (((size_t)s * W + (t >> 4)) * 64 + l) * K + k;
+  const size_t idx = ((((size_t)s * W + (t >> 4)) * 64 + l) << lgK) + k;
+  return (trace[idx] >> (2 * (t & 15))) & 3u;
 }
 
-// v1 walker: one lane chases the pointers through global memory, re-using the current dword.
-__global__ void traceback_walk(const TraceArgs a) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
+  const int d = threadIdx.x;
+  int lgK = 0;
+  while ((1 << lgK) < a.K) ++lgK;
   int i = a.m, j = a.n;
   if (a.kind == KIND_SW) {
     if (*a.sw_best <= 0) {
@@ -382,45 +387,61 @@ __global__ void traceback_walk(const TraceArgs a) {
       j = (int)(p & 0xffffffffu);
     }
   }
-  a.hdr[1] = i;
-  a.hdr[2] = j;
+  if (d == 0) {
+    a.hdr[1] = i;
+    a.hdr[2] = j;
+  }
   long long nops = 0;
-  size_t cur_idx = ~(size_t)0;
-  uint32_t cur = 0;
-  while (true) {
-    int code;
-    if (a.kind == KIND_SW) {
-      if (i == 0 || j == 0) break;  // border pointers are 'X' (main.cpp:1203-1204)
-    } else {
-      if (i == 0 && j == 0) break;
-    }
-    if (i == 0) {
-      code = 1;  // row 0: 'E'/'e' (main.cpp:727-728); LCS drain (main.cpp:1629-1634)
-    } else if (j == 0) {
-      code = 2;  // column 0: 'F'/'f' (main.cpp:609-616); LCS drain (main.cpp:1623-1628)
-    } else {
-      int sh;
-      const size_t idx = trace_word_index(i, j, a.K, a.W, sh);
-      if (idx != cur_idx) {
-        cur = a.trace[idx];
-        cur_idx = idx;
+  uint32_t warm = 0;
+  while (i > 0 && j > 0) {
+    const bool vM = (i - d >= 1) && (j - d >= 1);
+    const bool vE = (j - d >= 1);
+    const bool vF = (i - d >= 1);
+    const uint32_t cM = vM ? trace_code(a.trace, i - d, j - d, lgK, a.W) : 3u;
+    const uint32_t cE = vE ? trace_code(a.trace, i, j - d, lgK, a.W) : 3u;
+    const uint32_t cF = vF ? trace_code(a.trace, i - d, j, lgK, a.W) : 3u;
+    // touch the next 64 cells of this diagonal so the following iteration finds them in L2
+    if (i - d - 64 >= 1 && j - d - 64 >= 1) warm += trace_code(a.trace, i - d - 64, j - d - 64, lgK, a.W);
+    const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cM);
+    if (c0 == 3u) break;  // SW stop cell ('X', main.cpp:1233)
+    unsigned long long run;
+    if (c0 == 0u)
+      run = __ballot(cM == 0u);
+    else if (c0 == 1u)
+      run = __ballot(cE == 1u);
+    else
+      run = __ballot(cF == 2u);
+    const int L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);
+    if (d < L) a.ops[nops + d] = (uint8_t)c0;
+    nops += L;
+    if (c0 != 1u) i -= L;
+    if (c0 != 2u) j -= L;
+    // a diagonal run that ends inside the window also tells us the next move (the code of the
+    // cell that ended it); take that one move now instead of paying a round trip for it
+    if (c0 == 0u && L < 64) {
+      const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)cM, L);
+      if (cn == 1u || cn == 2u) {
+        if (d == 0) a.ops[nops] = (uint8_t)cn;
+        nops += 1;
+        if (cn == 1u) --j; else --i;
       }
-      code = (cur >> sh) & 3;
-      if (code == 3) break;  // SW stop cell
-    }
-    a.ops[nops++] = (uint8_t)code;
-    if (code == 0) {
-      --i;
-      --j;
-    } else if (code == 1) {
-      --j;
-    } else {
-      --i;
     }
   }
-  a.hdr[0] = nops;
-  a.hdr[3] = i;
-  a.hdr[4] = j;
+  if (warm == 0xffffffffu) a.hdr[7] = warm;  // keeps the warming loads alive; never true (codes are < 4)
+  if (a.kind != KIND_SW) {
+    // border walk: row 0 is all 'E'/'e' (main.cpp:727-728), column 0 all 'F'/'f' (main.cpp:609-616);
+    // LCS drains the same way (main.cpp:1623-1634)
+    const uint8_t code = (i == 0) ? 1 : 2;
+    const long long rest = (i == 0) ? j : i;
+    for (long long q = d; q < rest; q += 64) a.ops[nops + q] = code;
+    nops += rest;
+    i = j = 0;
+  }
+  if (d == 0) {
+    a.hdr[0] = nops;
+    a.hdr[3] = i;
+    a.hdr[4] = j;
+  }
 }
 
 }  // namespace sa
