@@ -1,0 +1,175 @@
+// aligner_main.cpp -- the `aligner` CLI of the reference (main.cpp:1720-1839), same flags, same
+// exit codes, same result files; the DP runs on one MI355X through libseqalign_hip.so.
+// No MPI: one process drives the GPU.
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <filesystem>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+
+#include "../../include/seqalign_hip.h"
+#include "../../include/seqalign_host.h"
+
+namespace {
+
+struct Options {
+  std::string query, target, outdir = ".";
+  int choice = -1;
+  int mode = SA_MODE_DNA;
+  bool verbose = false, binary = false, txt = false;
+  double gap_open = -5.0, gap_extend = -1.0;  // main.cpp:41-43
+  int device = 0;
+};
+
+struct Seq {
+  std::string header, residues;
+};
+
+Seq read_fasta(const std::string& path) {
+  char *h = nullptr, *s = nullptr;
+  int64_t len = 0;
+  if (sah_read_fasta(path.c_str(), &h, &s, &len) != 0) throw std::runtime_error("Error: Unable to open " + path);
+  Seq r{h, std::string(s, (size_t)len)};
+  sah_free(h);
+  sah_free(s);
+  return r;
+}
+
+// The reference reports bad residues by throwing from its score function (main.cpp:120-121);
+// main() catches, prints "Error: <what>" and still exits 0 (main.cpp:1832-1838).
+[[noreturn]] void throw_engine_error(sa_ctx* ctx, int rc, const sa_result& r, int mode) {
+  if (rc == SA_ERR_INVALID_CODE) {
+    std::string msg = mode == SA_MODE_DNA ? "Invalid DNA code: " : "Invalid protein code: ";
+    msg += (char)r.bad_x;
+    msg += ",";
+    msg += (char)r.bad_y;
+    throw std::runtime_error(msg);
+  }
+  throw std::runtime_error(std::string("GPU engine: ") + sa_last_error(ctx));
+}
+
+void run_one(sa_ctx* ctx, int which, const Options& o, const Seq& q, const Seq& t) {
+  sa_scoring sc = *sa_builtin_scoring(o.mode);
+  sc.gap_open = o.gap_open;
+  sc.gap_extend = o.gap_extend;
+  const uint8_t* x = (const uint8_t*)q.residues.data();
+  const uint8_t* y = (const uint8_t*)t.residues.data();
+  const int64_t m = (int64_t)q.residues.size(), n = (int64_t)t.residues.size();
+  const uint32_t flags = (o.binary || o.txt) ? SA_FLAG_KEEP_DP : 0u;
+  sa_result r;
+  const auto t0 = std::chrono::high_resolution_clock::now();
+  int rc;
+  if (which == 1)
+    rc = sa_nw(ctx, x, m, y, n, &sc, flags, &r);
+  else if (which == 2)
+    rc = sa_sw(ctx, x, m, y, n, &sc, flags, &r);
+  else
+    rc = sa_lcs(ctx, x, m, y, n, flags, &r);
+  const auto t1 = std::chrono::high_resolution_clock::now();
+  if (rc != SA_OK) throw_engine_error(ctx, rc, r, o.mode);
+  sah_job job{};
+  job.outdir = o.outdir.c_str();
+  job.header1 = q.header.c_str();
+  job.header2 = t.header.c_str();
+  job.mode = o.mode;
+  job.gap_open = o.gap_open;
+  job.gap_extend = o.gap_extend;
+  job.x = x;
+  job.m = m;
+  job.y = y;
+  job.n = n;
+  job.score = r.score;
+  job.end_i = r.end_i;
+  job.end_j = r.end_j;
+  job.ops = r.ops;
+  job.n_ops = r.n_ops;
+  job.time_ms = std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count();
+  job.verbose = o.verbose;
+  job.binary = o.binary;
+  job.txt = o.txt;
+  job.dp = r.dp;
+  if (which == 1)
+    sah_write_global(&job);
+  else if (which == 2)
+    sah_write_local(&job);
+  else
+    sah_write_lcs(&job);
+  sa_free_result(&r);
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  sa_ctx* ctx = nullptr;
+  try {
+    Options o;
+    for (int i = 1; i < argc; ++i) {  // main.cpp:1731-1776
+      const std::string arg = argv[i];
+      if (arg == "--query" && i + 1 < argc) {
+        o.query = argv[++i];
+      } else if (arg == "--target" && i + 1 < argc) {
+        o.target = argv[++i];
+      } else if (arg == "--choice" && i + 1 < argc) {
+        o.choice = std::stoi(argv[++i]);
+      } else if (arg == "--mode" && i + 1 < argc) {
+        const std::string v = argv[++i];
+        if (v == "dna") {
+          o.mode = SA_MODE_DNA;
+        } else if (v == "protein") {
+          o.mode = SA_MODE_PROTEIN;
+        } else {
+          std::cerr << "Unknown mode: " << v << "\n";
+          return 1;
+        }
+      } else if (arg == "--outdir" && i + 1 < argc) {
+        o.outdir = argv[++i];
+      } else if (arg == "--verbose") {
+        o.verbose = true;
+      } else if (arg == "--binary") {
+        o.binary = true;
+      } else if (arg == "--txt") {
+        o.txt = true;
+      } else if (arg == "--help") {
+        std::cout << "Usage: ./aligner --query <file1> --target <file2> --choice "
+                     "<1|2|3|4> [--mode dna|protein] [--outdir DIR] [--verbose]\n"
+                     "  --choice: 1=global, 2=local, 3=LCS, 4=all\n";
+        return 0;
+      } else if (arg == "--gap_open" && i + 1 < argc) {
+        o.gap_open = std::stod(argv[++i]);
+      } else if (arg == "--gap_extend" && i + 1 < argc) {
+        o.gap_extend = std::stod(argv[++i]);
+      } else if (arg == "--device" && i + 1 < argc) {  // extension: which GPU
+        o.device = std::stoi(argv[++i]);
+      } else {
+        std::cerr << "Unknown option: " << arg << "\n";
+        return 1;
+      }
+    }
+    if (o.query.empty() || o.target.empty() || o.choice == -1) {
+      std::cerr << "Missing required arguments: --query, --target, --choice\n";
+      return 1;
+    }
+    std::filesystem::create_directories(o.outdir);
+    const Seq q = read_fasta(o.query), t = read_fasta(o.target);
+    if (o.choice >= 1 && o.choice <= 4) {
+      ctx = sa_create(o.device);
+      if (!ctx) throw std::runtime_error("no gfx950 GPU available (this build has no CPU path)");
+      if (o.choice == 4) {
+        run_one(ctx, 1, o, q, t);
+        run_one(ctx, 2, o, q, t);
+        run_one(ctx, 3, o, q, t);
+      } else {
+        run_one(ctx, o.choice, o, q, t);
+      }
+    } else {
+      std::cerr << "Invalid method. Use --choice 1/2/3/4.\n";
+    }
+  } catch (const std::exception& e) {
+    std::cerr << "Error: " << e.what() << "\n";  // and exit 0, like the reference
+  }
+  if (ctx) sa_destroy(ctx);
+  return 0;
+}
