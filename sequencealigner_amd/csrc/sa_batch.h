@@ -1,0 +1,239 @@
+// sa_batch.h -- inter-task Smith-Waterman for many independent pairs (score + end cell only):
+// the first fill pass of the reference's localalign() (main.cpp:1099-1128) per pair.
+//
+// One wavefront per pair.  The pair's query (rows) is spread over the 64 lanes, K = ceil(m/64)
+// rows per lane (K is a template parameter, 1..16, pairs are grouped by K on the host), and the
+// wave sweeps the target with the same one-column-per-lane skew and DPP hand-off as the
+// single-pair kernel -- but nothing leaves the registers: no traceback codes, no strip hand-off.
+// Out-of-range columns need no predication: target positions outside [0,n) carry a PAD symbol
+// whose substitution score is -128 for every row, so with non-positive gap penalties cells left
+// of column 0 evaluate to exactly 0 (the reference's border) and cells right of column n-1 can
+// never beat, or tie ahead of, a real cell in the row-major order the reference uses.
+//
+// First-row-major-maximum tracking (main.cpp:1124-1127) costs two VALU ops per cell: every row
+// keeps max over columns of key = (H << CB) + (2^CB-1 - column); the larger key is the larger
+// score and, among equal scores, the smaller column.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <climits>
+#include <cstdint>
+
+#include "sa_kernels.h"
+
+namespace sa {
+
+struct PairDesc {
+  long long off_x, off_y;
+  int m, n;
+  int idx;   // position in the caller's arrays
+  int pad;
+};
+
+struct BatchArgs {
+  const uint8_t* seqs;
+  const PairDesc* desc;   // the pairs of this launch
+  int n_desc;
+  const int8_t* sub;      // alpha x alpha
+  const uint8_t* idx256;
+  int alpha;
+  int go, ge;
+  int CB;                 // column bits of the tracking key
+  int* score;
+  int* end_i;
+  int* end_j;
+  int* err;               // set to 1 if any pair had an invalid residue
+};
+
+constexpr int kBatchMaxN = 4095;  // LDS room for the encoded target; the host admits n <= kBatchMaxN - 200
+constexpr int kBatchMaxM = 1024;  // 64 lanes x 16 rows
+
+template <int K>
+struct BatchGeo {
+  static constexpr int PW = (K <= 4) ? 1 : (K <= 8 ? 2 : 4);  // profile dwords per (symbol, lane)
+  static constexpr int ROWB = 64 * PW * 4;
+};
+
+template <int K>
+__global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
+  using G = BatchGeo<K>;
+  extern __shared__ uint32_t lds[];
+  // LDS layout: prof[(alpha+1)][64][PW] dwords | yenc[kBatchMaxN + 192] bytes | map[256] | sub[alpha*alpha]
+  const int lane = threadIdx.x;
+  const PairDesc pd = a.desc[blockIdx.x];
+  const int m = pd.m, n = pd.n, alpha = a.alpha;
+  uint32_t* prof = lds;
+  uint8_t* yenc = reinterpret_cast<uint8_t*>(lds + (alpha + 1) * 64 * G::PW);
+  uint8_t* map = yenc + kBatchMaxN + 256;
+  int8_t* subt = reinterpret_cast<int8_t*>(map + 256);
+
+  for (int i = lane; i < 256; i += 64) map[i] = a.idx256[i];
+  for (int i = lane; i < alpha * alpha; i += 64) subt[i] = a.sub[i];
+  __syncthreads();
+
+  // encode the target; positions outside [0,n) get the PAD symbol (= alpha)
+  bool bad = false;
+  const uint8_t* y = a.seqs + pd.off_y;
+  const int ylen = ((n + 63 + 63) / 64) * 64 + 128;
+  for (int i = lane; i < ylen; i += 64) {
+    uint8_t v = (uint8_t)alpha;
+    if (i < n) {
+      v = map[y[i]];
+      bad |= (v == 255);
+      if (v == 255) v = 0;
+    }
+    yenc[i] = v;
+  }
+  // query profile of this lane's K rows
+  const uint8_t* x = a.seqs + pd.off_x;
+  int xi[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int r = lane * K + k;
+    int v = -1;
+    if (r < m) {
+      v = map[x[r]];
+      bad |= (v == 255);
+      if (v == 255) v = 0;
+    }
+    xi[k] = v;
+  }
+  for (int sym = 0; sym <= alpha; ++sym) {
+    uint32_t w[G::PW];
+#pragma unroll
+    for (int i = 0; i < G::PW; ++i) w[i] = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      int v = (sym == alpha) ? -128 : (xi[k] < 0 ? 0 : (int)subt[xi[k] * alpha + sym]);
+      w[k / 4] |= (uint32_t)(uint8_t)(int8_t)v << (8 * (k & 3));
+    }
+#pragma unroll
+    for (int i = 0; i < G::PW; ++i) prof[(sym * 64 + lane) * G::PW + i] = w[i];
+  }
+  __syncthreads();
+
+  const char* ldsLane = reinterpret_cast<const char*>(prof) + lane * 4 * G::PW;
+  const int go = a.go, ge = a.ge, CB = a.CB;
+  int H[K], E[K];
+  uint32_t bk[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    H[k] = 0;
+    E[k] = 0;
+    bk[k] = 0;
+  }
+  int passH = 0, passF = 0, dprev = 0;
+  int ypass = alpha * G::ROWB;
+  const int cbase = (1 << CB) - 64;  // key low bits = cbase - column >= 0 for every column the sweep touches
+  int cinv = cbase + lane;           // column = t - lane
+  const int nsteps = ((n + 63 + 15) / 16) * 16;
+  int yb = 0;
+
+  auto load_prof = [&](int yv, uint32_t (&pw)[G::PW]) {
+    if (G::PW == 1) {
+      pw[0] = *reinterpret_cast<const uint32_t*>(ldsLane + yv);
+    } else if (G::PW == 2) {
+      const uint2 t = *reinterpret_cast<const uint2*>(ldsLane + yv);
+      pw[0] = t.x;
+      pw[G::PW - 1] = t.y;
+    } else {
+      const uint4 t = *reinterpret_cast<const uint4*>(ldsLane + yv);
+      pw[0] = t.x;
+      pw[1 % G::PW] = t.y;
+      pw[2 % G::PW] = t.z;
+      pw[3 % G::PW] = t.w;
+    }
+  };
+
+  // software pipeline: the profile word of step t+1 is fetched from LDS while step t computes
+  yb = (int)yenc[lane] * G::ROWB;
+  int yv = dpp_shr1(yb, ypass);
+  yb = dpp_shl1(yb, yb);
+  uint32_t pw[G::PW];
+  load_prof(yv, pw);
+
+#pragma unroll 1
+  for (int t0 = 0; t0 < nsteps; t0 += 16) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int t = t0 + u;
+      // hand-off from the lane above (values of the previous step); lane 0 sees the zero border
+      int up = dpp_shr1(0, passH);
+      int uf = dpp_shr1(0, passF);
+      // next step's symbol and profile word
+      if (u == 15 && ((t0 + 16) & 63) == 0) yb = (int)yenc[t + 1 + lane] * G::ROWB;
+      ypass = yv;
+      const int yv_next = dpp_shr1(yb, ypass);
+      yb = dpp_shl1(yb, yb);
+      uint32_t pw_next[G::PW];
+      load_prof(yv_next, pw_next);
+
+      int diag = dprev;
+      dprev = up;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int sg = (int)(int8_t)(pw[k / 4] >> (8 * (k & 3)));
+        const int left = H[k];
+        const int f = max(max(up + go, uf + ge), 0);
+        const int e = max(max(left + go, E[k] + ge), 0);
+        const int h = max(max(diag + sg, e), f);
+        bk[k] = max(bk[k], ((uint32_t)h << CB) + (uint32_t)cinv);
+        E[k] = e;
+        diag = left;
+        H[k] = h;
+        up = h;
+        uf = f;
+      }
+      passH = up;
+      passF = uf;
+      --cinv;
+      yv = yv_next;
+#pragma unroll
+      for (int i = 0; i < G::PW; ++i) pw[i] = pw_next[i];
+    }
+  }
+
+  // per lane: first row (ascending) with the best score; keys of rows >= m are ignored
+  const uint32_t cmask = (1u << CB) - 1u;
+  int bs = 0, brow = 0, bcol = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int r = lane * K + k;
+    const int s = (int)(bk[k] >> CB);
+    if (r < m && s > bs) {
+      bs = s;
+      brow = r;
+      bcol = cbase - (int)(bk[k] & cmask);
+    }
+  }
+  unsigned long long key = bs > 0 ? (((unsigned long long)(uint32_t)bs << 32) | ((unsigned long long)(0xffffu - brow) << 16) |
+                                     (unsigned long long)(0xffffu - bcol))
+                                  : 0ull;
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(key, o);
+    key = other > key ? other : key;
+  }
+  const unsigned long long anybad = __ballot(bad);
+  if (lane == 0) {
+    if (anybad) {
+      a.score[pd.idx] = INT_MIN;
+      a.end_i[pd.idx] = 0;
+      a.end_j[pd.idx] = 0;
+      *a.err = 1;
+    } else if (key == 0ull) {
+      a.score[pd.idx] = 0;
+      a.end_i[pd.idx] = 0;
+      a.end_j[pd.idx] = 0;
+    } else {
+      a.score[pd.idx] = (int)(key >> 32);
+      a.end_i[pd.idx] = (int)(0xffffu - ((key >> 16) & 0xffffu)) + 1;
+      a.end_j[pd.idx] = (int)(0xffffu - (key & 0xffffu)) + 1;
+    }
+  }
+}
+
+template <int K>
+inline size_t batch_lds_bytes(int alpha) {
+  return (size_t)(alpha + 1) * 64 * BatchGeo<K>::PW * 4 + (kBatchMaxN + 256) + 256 + (size_t)alpha * alpha + 16;
+}
+
+}  // namespace sa

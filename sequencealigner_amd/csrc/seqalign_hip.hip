@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "../../include/seqalign_hip.h"
+#include "sa_batch.h"
 #include "sa_kernels.h"
 #include "sa_tables.h"
 
@@ -406,6 +407,165 @@ int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t
   return SA_OK;
 }
 
+
+template <int K>
+void launch_batch(hipStream_t st, int count, int alpha, const BatchArgs& a) {
+  hipLaunchKernelGGL(sw_batch_kernel<K>, dim3(count), dim3(64), batch_lds_bytes<K>(alpha), st, a);
+}
+
+void launch_batch_k(int K, hipStream_t st, int count, int alpha, const BatchArgs& a) {
+  switch (K) {
+    case 1: launch_batch<1>(st, count, alpha, a); break;
+    case 2: launch_batch<2>(st, count, alpha, a); break;
+    case 3: launch_batch<3>(st, count, alpha, a); break;
+    case 4: launch_batch<4>(st, count, alpha, a); break;
+    case 5: launch_batch<5>(st, count, alpha, a); break;
+    case 6: launch_batch<6>(st, count, alpha, a); break;
+    case 7: launch_batch<7>(st, count, alpha, a); break;
+    case 8: launch_batch<8>(st, count, alpha, a); break;
+    case 9: launch_batch<9>(st, count, alpha, a); break;
+    case 10: launch_batch<10>(st, count, alpha, a); break;
+    case 11: launch_batch<11>(st, count, alpha, a); break;
+    case 12: launch_batch<12>(st, count, alpha, a); break;
+    case 13: launch_batch<13>(st, count, alpha, a); break;
+    case 14: launch_batch<14>(st, count, alpha, a); break;
+    case 15: launch_batch<15>(st, count, alpha, a); break;
+    default: launch_batch<16>(st, count, alpha, a); break;
+  }
+}
+
+// Many independent pairs: one wavefront per pair (sa_batch.h).  Pairs the fast kernel does not
+// admit (query > 1024 rows, very long target) go through the single-pair SW kernels, score only.
+int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x, const int64_t* off_y,
+              const int32_t* len_y, int64_t n_pairs, const sa_scoring* sc, int32_t* score, int32_t* end_i, int32_t* end_j,
+              float* kernel_ms) {
+  if (!ctx) return SA_ERR_ARG;
+  if (kernel_ms) *kernel_ms = 0.f;
+  if (n_pairs < 0 || (n_pairs > 0 && (!seqs || !off_x || !len_x || !off_y || !len_y || !score || !end_i || !end_j)))
+    return fail(ctx, SA_ERR_ARG, "bad batch arguments");
+  if (!sc || !sc->sub || !sc->idx256 || sc->alpha < 1 || sc->alpha > 31) return fail(ctx, SA_ERR_ARG, "bad scoring");
+  if (sc->gap_open != std::floor(sc->gap_open) || sc->gap_extend != std::floor(sc->gap_extend))
+    return fail(ctx, SA_ERR_UNSUPPORTED, "fractional gap penalties are not implemented on the batch path");
+  if (sc->gap_open > 0 || sc->gap_extend > 0 || sc->gap_open < -1e6 || sc->gap_extend < -1e6)
+    return fail(ctx, SA_ERR_ARG, "batch path needs non-positive gap penalties");
+  if (n_pairs == 0) return SA_OK;
+  if (n_pairs > 0x7fffff00LL) return fail(ctx, SA_ERR_ARG, "too many pairs");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int alpha = sc->alpha;
+
+  // group by rows-per-lane K = ceil(m/64); counting sort keeps the caller's order inside a group
+  std::vector<PairDesc> desc;
+  desc.reserve((size_t)n_pairs);
+  std::vector<int64_t> slow;
+  std::vector<int> group_count(17, 0), group_nmax(17, 0);
+  int64_t pool_end = 0;
+  for (int64_t k = 0; k < n_pairs; ++k) {
+    if (len_x[k] < 0 || len_y[k] < 0 || off_x[k] < 0 || off_y[k] < 0) return fail(ctx, SA_ERR_ARG, "negative offset/length in pair %lld", (long long)k);
+    pool_end = std::max(pool_end, std::max(off_x[k] + len_x[k], off_y[k] + len_y[k]));
+    if (len_x[k] == 0 || len_y[k] == 0) {
+      score[k] = 0;
+      end_i[k] = end_j[k] = 0;
+    } else if (len_x[k] > kBatchMaxM || len_y[k] > kBatchMaxN - 200) {
+      slow.push_back(k);
+    } else {
+      const int K = (len_x[k] + 63) / 64;
+      ++group_count[K];
+      group_nmax[K] = std::max(group_nmax[K], len_y[k]);
+    }
+  }
+  std::vector<int> group_start(18, 0);
+  for (int K = 16; K >= 1; --K) group_start[K - 1 >= 0 ? K - 1 : 0] = 0;  // (filled below)
+  {
+    int acc = 0;
+    for (int K = 16; K >= 1; --K) {  // big pairs first
+      group_start[K] = acc;
+      acc += group_count[K];
+    }
+    desc.resize((size_t)acc);
+    std::vector<int> cur(group_start.begin(), group_start.end());
+    for (int64_t k = 0; k < n_pairs; ++k) {
+      if (len_x[k] == 0 || len_y[k] == 0 || len_x[k] > kBatchMaxM || len_y[k] > kBatchMaxN - 200) continue;
+      const int K = (len_x[k] + 63) / 64;
+      desc[(size_t)cur[K]++] = PairDesc{off_x[k], off_y[k], len_x[k], len_y[k], (int)k, 0};
+    }
+  }
+
+  int rc = SA_OK;
+  int h_err = 0;
+  if (!desc.empty()) {
+    if ((rc = ensure(ctx, ctx->b_seq, (size_t)pool_end + 64))) return rc;
+    if ((rc = ensure(ctx, ctx->b_desc, desc.size() * sizeof(PairDesc)))) return rc;
+    if ((rc = ensure(ctx, ctx->b_out, (size_t)n_pairs * 12 + 1024 + 2048))) return rc;
+    HIPCK(ctx, hipMemcpyAsync(ctx->b_seq.p, seqs, (size_t)pool_end, hipMemcpyHostToDevice, st));
+    HIPCK(ctx, hipMemcpyAsync(ctx->b_desc.p, desc.data(), desc.size() * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+    int* d_score = (int*)ctx->b_out.p;
+    int* d_ei = d_score + n_pairs;
+    int* d_ej = d_ei + n_pairs;
+    int* d_err = d_ej + n_pairs;
+    int8_t* d_sub = (int8_t*)(d_err + 16);
+    uint8_t* d_map = (uint8_t*)(d_sub + 1024);
+    HIPCK(ctx, hipMemsetAsync(d_err, 0, 64, st));
+    HIPCK(ctx, hipMemcpyAsync(d_sub, sc->sub, (size_t)alpha * alpha, hipMemcpyHostToDevice, st));
+    HIPCK(ctx, hipMemcpyAsync(d_map, sc->idx256, 256, hipMemcpyHostToDevice, st));
+    BatchArgs a{};
+    a.seqs = (const uint8_t*)ctx->b_seq.p;
+    a.sub = d_sub;
+    a.idx256 = d_map;
+    a.alpha = alpha;
+    a.go = (int)sc->gap_open;
+    a.ge = (int)sc->gap_extend;
+    a.score = d_score;
+    a.end_i = d_ei;
+    a.end_j = d_ej;
+    a.err = d_err;
+    HIPCK(ctx, hipEventRecord(ctx->ev[0], st));
+    for (int K = 16; K >= 1; --K) {
+      if (!group_count[K]) continue;
+      a.desc = (const PairDesc*)ctx->b_desc.p + group_start[K];
+      a.n_desc = group_count[K];
+      int CB = 8;
+      while ((1 << CB) < group_nmax[K] + 160) ++CB;
+      a.CB = CB;
+      launch_batch_k(K, st, group_count[K], alpha, a);
+    }
+    HIPCK(ctx, hipGetLastError());
+    HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
+    // results come back for every index; slots of pairs handled elsewhere are overwritten below
+    std::vector<int> h_out((size_t)n_pairs * 3);
+    HIPCK(ctx, hipMemcpyAsync(h_out.data(), d_score, (size_t)n_pairs * 12, hipMemcpyDeviceToHost, st));
+    HIPCK(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
+    HIPCK(ctx, hipStreamSynchronize(st));
+    float ms = 0;
+    HIPCK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+    if (kernel_ms) *kernel_ms = ms;
+    for (const PairDesc& d : desc) {
+      score[d.idx] = h_out[(size_t)d.idx];
+      end_i[d.idx] = h_out[(size_t)n_pairs + d.idx];
+      end_j[d.idx] = h_out[(size_t)2 * n_pairs + d.idx];
+    }
+  }
+  for (int64_t k : slow) {
+    sa_result r;
+    const int rc1 = run_pair(ctx, KIND_SW, seqs + off_x[k], len_x[k], seqs + off_y[k], len_y[k], sc, SA_FLAG_NO_TRACEBACK, &r);
+    if (rc1 == SA_OK) {
+      score[k] = (int32_t)r.score;
+      end_i[k] = (int32_t)r.end_i;
+      end_j[k] = (int32_t)r.end_j;
+      if (kernel_ms) *kernel_ms += r.kernel_fill_ms;
+    } else if (rc1 == SA_ERR_INVALID_CODE) {
+      score[k] = INT32_MIN;
+      end_i[k] = end_j[k] = 0;
+      h_err = 1;
+    } else {
+      return rc1;
+    }
+    sa_free_result(&r);
+  }
+  if (h_err) return fail(ctx, SA_ERR_INVALID_CODE, "at least one pair holds a residue outside the scoring alphabet (its score is INT32_MIN)");
+  return SA_OK;
+}
+
 struct Builtin {
   int8_t sub[2][32 * 32];
   uint8_t map[2][256];
@@ -518,8 +678,7 @@ int sa_lcs(sa_ctx* ctx, const uint8_t* x, int64_t m, const uint8_t* y, int64_t n
 int sa_sw_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x, const int64_t* off_y,
                 const int32_t* len_y, int64_t n_pairs, const sa_scoring* sc, int32_t* score, int32_t* end_i,
                 int32_t* end_j, float* kernel_ms) {
-  (void)seqs; (void)off_x; (void)len_x; (void)off_y; (void)len_y; (void)n_pairs; (void)sc; (void)score; (void)end_i; (void)end_j; (void)kernel_ms;
-  return fail(ctx, SA_ERR_UNSUPPORTED, "sa_sw_batch: not implemented yet");
+  return run_batch(ctx, seqs, off_x, len_x, off_y, len_y, n_pairs, sc, score, end_i, end_j, kernel_ms);
 }
 
 }  // extern "C"
