@@ -48,8 +48,13 @@ extern "C" {
 
 /* flags */
 #define SA_FLAG_KEEP_DP 1u  /* also return the full (m+1)x(n+1) int32 S (or LCS L) matrix:
-                               what --binary/--txt dump (main.cpp:825-831, 1364-1368, 1686-1691) */
+                               what --binary/--txt dump (main.cpp:825-831, 1364-1368, 1686-1691);
+                               limited to 1.5e9 cells */
 #define SA_FLAG_NO_TRACEBACK 2u /* score (and SW end cell) only */
+
+#define SA_KIND_NW 0
+#define SA_KIND_SW 1
+#define SA_KIND_LCS 2
 
 typedef struct sa_ctx sa_ctx;
 
@@ -118,6 +123,43 @@ int sa_sw_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const in
                 const int64_t* off_y, const int32_t* len_y, int64_t n_pairs,
                 const sa_scoring* sc, int32_t* score, int32_t* end_i, int32_t* end_j,
                 float* kernel_ms);
+
+/* ---- one long pair over several GPUs: column stripes ----
+ *
+ * Replaces the reference's MPI row-block chain (main.cpp:1050-1147, 1151-1177), which is serial;
+ * here GPU g owns the columns [col_begin, col_begin+n_stripe) of the same matrix and every
+ * process (one per GPU) calls sa_stripe_fill on its own stripe.  The only data that crosses
+ * GPUs is the stripe's border column: for every matrix row i = 1..m the pair (H[i][c], E[i][c])
+ * at the stripe's last column, 8 bytes per row, laid out as int32[m+1][2] (entry 0 is written by
+ * the library).  The library does not move it: while it enqueues the fill it calls on_event
+ *   SA_EV_NEED_LEFT(k)   before the first launch that reads rows of chunk k of `left`
+ *   SA_EV_RIGHT_READY(k) after the launch that completes rows of chunk k of `right`
+ * (chunk k = matrix rows k*chunk_rows+1 .. min(m,(k+1)*chunk_rows), both in ascending k) and the
+ * caller enqueues the recv / send of that chunk on the ctx's stream (RCCL send/recv, a peer
+ * copy, ...).  NW and LCS; the score is valid on the last stripe.
+ * sa_stripe_traceback walks this stripe's codes from (start_i, start_j) (j local to the stripe,
+ * 1-based) and stops at the stripe's left edge unless it is the first stripe; out->start_i is
+ * the row to continue from on the stripe to the left (at its last column).  The op lists of the
+ * stripes, concatenated right to left, are the op list sa_nw / sa_lcs return for the whole pair.
+ */
+#define SA_EV_NEED_LEFT 0
+#define SA_EV_RIGHT_READY 1
+typedef int (*sa_stripe_event_fn)(void* user, int event, int64_t chunk); /* return 0 to continue */
+
+typedef struct {
+  int64_t n_total;       /* columns of the whole matrix */
+  int64_t col_begin;     /* first column of this stripe, 0-based */
+  int32_t is_first, is_last;
+  const int32_t* left;   /* device int32[m+1][2], NULL iff is_first */
+  int32_t* right;        /* device int32[m+1][2], NULL iff is_last */
+  int64_t chunk_rows;
+  sa_stripe_event_fn on_event;
+  void* user;
+} sa_stripe_desc;
+
+int sa_stripe_fill(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m, const uint8_t* y_stripe, int64_t n_stripe,
+                   const sa_scoring* sc, const sa_stripe_desc* desc, sa_result* out);
+int sa_stripe_traceback(sa_ctx* ctx, int64_t start_i, int64_t start_j, sa_result* out);
 
 #ifdef __cplusplus
 }

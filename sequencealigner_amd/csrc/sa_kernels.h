@@ -34,13 +34,16 @@ struct FillArgs {
   int m, n;   // rows, columns
   int S, C;   // strips, steps per tile (multiple of 64)
   int W;      // trace dwords per (lane,k) per strip
-  int go, ge; // integer gap penalties (negative)
+  int go, ge; // gap penalties; with FRAC: floor() of the reference's doubles
+  int fo, fe; // FRAC: 1 if the open / extend penalty has a fractional part
   int alpha;  // profile symbols
   int NP;     // length of one bottom-row ring buffer
   const uint8_t* yenc;   // NW/SW: table index per column; LCS: raw byte.  Padded with zeros.
   const uint32_t* prof;  // NW/SW: [S][alpha][64][PW] dwords
   const uint8_t* xpad;   // LCS: raw query bytes padded to S*64*K
-  const int* colb;       // H[i][0], i = 0 .. S*64*K
+  const int2* lb;        // left border per matrix row i = 0..m: (H[i][0], E[i][0]) of this stripe
+  int2* rb;              // optional: right border out, (H[i][n], E[i][n]) for i = 1..m (column stripes)
+  int* dp;               // optional (DUMP): (m+1)x(n+1) row-major S / L matrix, interior cells
   int* botH;             // [2][NP]  bottom row H of strip s lives in buffer s&1, index p = c+64
   int* botF;             // [2][NP]
   int* state;            // [S][NF][64] lane state carried from tile to tile
@@ -56,6 +59,18 @@ __device__ __forceinline__ int dpp_shr1(int old, int src) {  // lane l <- src of
 }
 __device__ __forceinline__ int dpp_shl1(int old, int src) {  // lane l <- src of lane l+1, lane 63 <- old
   return __builtin_amdgcn_update_dpp(old, src, 0x130, 0xf, 0xf, false);
+}
+
+enum { FLAG_FRAC = 1, FLAG_DUMP = 2 };
+
+// score + gap.  The reference adds a double penalty to an int and truncates the sum toward
+// zero (main.cpp:603-604, 625-634, 958-964).  With g = G + f, G = floor(g), 0 < f < 1:
+// trunc(v + g) = w for w >= 0 and w + 1 for w < 0, where w = v + G.
+template <bool FRAC>
+__device__ __forceinline__ int add_gap(int v, int G, int has_frac) {
+  const int w = v + G;
+  if (!FRAC) return w;
+  return w + (((unsigned)w >> 31) & (unsigned)has_frac);
 }
 
 template <int KIND, int K>
@@ -79,11 +94,13 @@ struct Lane {
 };
 
 // One skewed step of one lane: K cells of column c.
-template <int KIND, int K, bool BND>
+template <int KIND, int K, bool BND, int FLAGS>
 __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF, int& yb, int& obH, int& obF,
                                           uint32_t (&tacc)[K], const int u, const char* ldsLane,
-                                          const uint32_t (&xr)[K], const int go, const int ge, const int c,
-                                          const int n) {
+                                          const uint32_t (&xr)[K], const FillArgs& a, const int c, int* dprow) {
+  constexpr bool FRAC = (FLAGS & FLAG_FRAC) != 0;
+  constexpr bool DUMP = (FLAGS & FLAG_DUMP) != 0;
+  const int go = a.go, ge = a.ge, n = a.n;
   using G = Geo<KIND, K>;
   int up = dpp_shr1(ibH, st.passH);
   int uf = 0;
@@ -118,8 +135,8 @@ __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF,
       code = eq ? 0 : (up >= left ? 2 : 1);
     } else {
       const int sg = (int)(int8_t)(pw[k / 4] >> (8 * (k & 3)));
-      int f = max(up + go, uf + ge);
-      int e = max(left + go, st.E[k] + ge);
+      int f = max(add_gap<FRAC>(up, go, a.fo), add_gap<FRAC>(uf, ge, a.fe));
+      int e = max(add_gap<FRAC>(left, go, a.fo), add_gap<FRAC>(st.E[k], ge, a.fe));
       int mv = diag + sg;
       if (KIND == KIND_SW) {
         f = max(f, 0);
@@ -145,6 +162,9 @@ __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF,
       st.bestc[k] = better ? c : st.bestc[k];
     }
     tacc[k] |= (uint32_t)code << (2 * u);
+    if (DUMP) {
+      if (act && dprow[k] >= 0) a.dp[(size_t)dprow[k] + c + 1] = h;
+    }
     diag = left;
     st.H[k] = h;
     up = h;
@@ -168,9 +188,9 @@ __device__ __forceinline__ void store_trace(uint32_t* dst, const uint32_t (&t)[K
 }
 
 // 64 steps of one strip (one bottom-row hand-off in, one out).
-template <int KIND, int K, bool BND>
+template <int KIND, int K, bool BND, int FLAGS>
 __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, const int s, const int Tb,
-                                          const int lane, const char* ldsLane, const uint32_t (&xr)[K]) {
+                                          const int lane, const char* ldsLane, const uint32_t (&xr)[K], int* dprow) {
   using G = Geo<KIND, K>;
   const int* rdH = a.botH + (size_t)((s & 1) ^ 1) * a.NP;
   const int* rdF = a.botF + (size_t)((s & 1) ^ 1) * a.NP;
@@ -190,7 +210,7 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
     const int cbase = Tb + 16 * sub - lane;
 #pragma unroll
     for (int u = 0; u < 16; ++u)
-      lane_step<KIND, K, BND>(st, ibH, ibF, yb, obH, obF, tacc, u, ldsLane, xr, a.go, a.ge, cbase + u, a.n);
+      lane_step<KIND, K, BND, FLAGS>(st, ibH, ibF, yb, obH, obF, tacc, u, ldsLane, xr, a, cbase + u, dprow);
     store_trace<K>(tdst, tacc);
     tdst += 64 * K;
   }
@@ -198,8 +218,9 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
   if (KIND != KIND_LCS) wrF[Tb + 1 + lane] = obF;
 }
 
-template <int KIND, int K>
+template <int KIND, int K, int FLAGS>
 __global__ void __launch_bounds__(64) fill_tile(const FillArgs a) {
+  constexpr bool DUMP = (FLAGS & FLAG_DUMP) != 0;
   using G = Geo<KIND, K>;
   extern __shared__ uint32_t lds[];
   const int lane = threadIdx.x;
@@ -225,20 +246,25 @@ __global__ void __launch_bounds__(64) fill_tile(const FillArgs a) {
   }
   const char* ldsLane = reinterpret_cast<const char*>(lds) + lane * 4 * G::PW;
 
+  int dprow[K];  // DUMP: offset of the lane's rows in the dp matrix, -1 for padding rows
+#pragma unroll
+  for (int k = 0; k < K; ++k) dprow[k] = (DUMP && r0 + k < a.m) ? (r0 + k + 1) * (a.n + 1) : -1;
+
   Lane<KIND, K> st;
   int* sp = a.state + ((size_t)s * G::NF) * 64 + lane;
   if (q == qmin) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      st.H[k] = a.colb[r0 + k + 1];
-      st.E[k] = (KIND == KIND_NW) ? kNeg : 0;
+      const int2 b = a.lb[min(r0 + k + 1, a.m)];
+      st.H[k] = b.x;
+      st.E[k] = b.y;
       st.best[k] = 0;
       st.bestc[k] = -1;
     }
     st.passH = st.H[K - 1];
     st.passF = (KIND == KIND_NW) ? kNeg : 0;
     st.ypass = 0;
-    st.dprev = a.colb[r0];
+    st.dprev = a.lb[min(r0, a.m)].x;
   } else {
     int f = 0;
 #pragma unroll
@@ -264,14 +290,19 @@ __global__ void __launch_bounds__(64) fill_tile(const FillArgs a) {
     const int Tb = T0 + 64 * b;
     if (Tb < 0) continue;
     if (Tb >= a.n + 63) break;
-    const bool interior = (Tb >= 64) && (Tb + 63 < a.n);
+    const bool interior = !DUMP && (Tb >= 64) && (Tb + 63 < a.n);
     if (interior)
-      run_block<KIND, K, false>(st, a, s, Tb, lane, ldsLane, xr);
+      run_block<KIND, K, false, FLAGS>(st, a, s, Tb, lane, ldsLane, xr, dprow);
     else
-      run_block<KIND, K, true>(st, a, s, Tb, lane, ldsLane, xr);
+      run_block<KIND, K, true, FLAGS>(st, a, s, Tb, lane, ldsLane, xr, dprow);
   }
 
   if (q == qmax) {
+    if (a.rb) {  // column stripes: the lane's rows froze at the stripe's last column
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (r0 + k < a.m) a.rb[r0 + k + 1] = make_int2(st.H[k], st.E[k]);
+    }
     if (KIND == KIND_SW) {
 #pragma unroll
       for (int k = 0; k < K; ++k)
@@ -352,6 +383,8 @@ __global__ void sw_reduce_pos(const int* __restrict__ rowbest, const int* __rest
 // ---- traceback ----
 struct TraceArgs {
   int kind, m, n, K, W;
+  int start_i, start_j;   // < 0: default start (NW/LCS: (m,n); SW: the reduced best cell)
+  int stop_at_col0;       // column stripes (not the first): stop when j reaches 0 and hand i over
   const uint32_t* trace;
   const int* sw_best;                  // SW: best score (device)
   const unsigned long long* sw_pos;    // SW: (i<<32)|j of the end cell (device)
@@ -378,7 +411,10 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
   int lgK = 0;
   while ((1 << lgK) < a.K) ++lgK;
   int i = a.m, j = a.n;
-  if (a.kind == KIND_SW) {
+  if (a.start_i >= 0) {
+    i = a.start_i;
+    j = a.start_j;
+  } else if (a.kind == KIND_SW) {
     if (*a.sw_best <= 0) {
       i = j = 0;
     } else {
@@ -428,7 +464,13 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
     }
   }
   if (warm == 0xffffffffu) a.hdr[7] = warm;  // keeps the warming loads alive; never true (codes are < 4)
-  if (a.kind != KIND_SW) {
+  if (a.kind != KIND_SW && a.stop_at_col0) {
+    if (i == 0) {  // row 0 of the matrix: left moves to the stripe's edge
+      for (long long q = d; q < j; q += 64) a.ops[nops + q] = 1;
+      nops += j;
+      j = 0;
+    }
+  } else if (a.kind != KIND_SW) {
     // border walk: row 0 is all 'E'/'e' (main.cpp:727-728), column 0 all 'F'/'f' (main.cpp:609-616);
     // LCS drains the same way (main.cpp:1623-1634)
     const uint8_t code = (i == 0) ? 1 : 2;

@@ -42,8 +42,11 @@ struct sa_ctx {
   Buf xenc, yenc, prof, sub, colb, bot, state, trace, rowbest, small, ops;
   // batch workspaces
   Buf b_seq, b_desc, b_out;
-  // pinned host staging
-  void* h_small = nullptr;
+  Buf lbuf, dpbuf;
+  // geometry of the last fill, for the traceback that follows it
+  struct {
+    int valid = 0, kind = 0, m = 0, n = 0, K = 0, W = 0, first_stripe = 1;
+  } last;
 };
 
 namespace {
@@ -125,12 +128,21 @@ Tuning choose_tuning(const sa_ctx* ctx, int kind, int64_t m, int64_t n) {
 }
 
 template <int KIND>
-void launch_fill(int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a) {
-  switch (K) {
-    case 1: hipLaunchKernelGGL((fill_tile<KIND, 1>), grid, dim3(64), lds, st, a); break;
-    case 2: hipLaunchKernelGGL((fill_tile<KIND, 2>), grid, dim3(64), lds, st, a); break;
-    case 4: hipLaunchKernelGGL((fill_tile<KIND, 4>), grid, dim3(64), lds, st, a); break;
-    default: hipLaunchKernelGGL((fill_tile<KIND, 8>), grid, dim3(64), lds, st, a); break;
+void launch_fill(int K, int fl, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a) {
+  // instantiated combinations: plain K in {1,2,4,8}; FRAC only with K=2; DUMP (+FRAC) only with K=1
+  if (fl == 0) {
+    switch (K) {
+      case 1: hipLaunchKernelGGL((fill_tile<KIND, 1, 0>), grid, dim3(64), lds, st, a); break;
+      case 2: hipLaunchKernelGGL((fill_tile<KIND, 2, 0>), grid, dim3(64), lds, st, a); break;
+      case 4: hipLaunchKernelGGL((fill_tile<KIND, 4, 0>), grid, dim3(64), lds, st, a); break;
+      default: hipLaunchKernelGGL((fill_tile<KIND, 8, 0>), grid, dim3(64), lds, st, a); break;
+    }
+  } else if (fl == FLAG_FRAC) {
+    hipLaunchKernelGGL((fill_tile<KIND, 2, FLAG_FRAC>), grid, dim3(64), lds, st, a);
+  } else if (fl == FLAG_DUMP) {
+    hipLaunchKernelGGL((fill_tile<KIND, 1, FLAG_DUMP>), grid, dim3(64), lds, st, a);
+  } else {
+    hipLaunchKernelGGL((fill_tile<KIND, 1, FLAG_DUMP | FLAG_FRAC>), grid, dim3(64), lds, st, a);
   }
 }
 
@@ -190,51 +202,47 @@ void border_only_result(int kind, int64_t m, int64_t n, const std::vector<int>& 
   }
 }
 
-int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t* y, int64_t n64,
-             const sa_scoring* sc, uint32_t flags, sa_result* out) {
-  if (!ctx) return SA_ERR_ARG;
-  if (!out) return fail(ctx, SA_ERR_ARG, "out is NULL");
-  memset(out, 0, sizeof *out);
-  if (m64 < 0 || n64 < 0 || (m64 > 0 && !x) || (n64 > 0 && !y)) return fail(ctx, SA_ERR_ARG, "bad sequence arguments");
-  if (m64 > 0x7ff00000LL || n64 > 0x7ff00000LL) return fail(ctx, SA_ERR_ARG, "sequence longer than int32 indexing (reference Q7)");
-  if (flags & SA_FLAG_KEEP_DP) return fail(ctx, SA_ERR_UNSUPPORTED, "SA_FLAG_KEEP_DP is not implemented yet");
-  const int m = (int)m64, n = (int)n64;
-  int go = 0, ge = 0, alpha = 1;
-  if (kind != KIND_LCS) {
-    if (!sc || !sc->sub || !sc->idx256 || sc->alpha < 1 || sc->alpha > 32) return fail(ctx, SA_ERR_ARG, "bad scoring");
-    if (sc->gap_open != std::floor(sc->gap_open) || sc->gap_extend != std::floor(sc->gap_extend))
-      return fail(ctx, SA_ERR_UNSUPPORTED,
-                  "fractional gap penalties (%g, %g) need the reference's per-op truncation; not implemented on the GPU path yet",
-                  sc->gap_open, sc->gap_extend);
-    if (std::fabs(sc->gap_open) > 1e6 || std::fabs(sc->gap_extend) > 1e6) return fail(ctx, SA_ERR_ARG, "gap penalty out of range");
-    go = (int)sc->gap_open;
-    ge = (int)sc->gap_extend;
-    alpha = sc->alpha;
-    const double worst = ((double)m + n + 2) * std::max({std::fabs((double)go), std::fabs((double)ge), 128.0});
-    if (worst > 1.0e9) return fail(ctx, SA_ERR_ARG, "score range would overflow int32");
-    if (first_invalid_pair(x, m, y, n, sc->idx256, &out->bad_x, &out->bad_y))
-      return fail(ctx, SA_ERR_INVALID_CODE, "invalid residue pair %c,%c", out->bad_x, out->bad_y);
-  }
+struct StripeDesc {  // internal mirror of sa_stripe_desc; all-null = the whole matrix on this GPU
+  int64_t n_total = 0, col_begin = 0;
+  int is_first = 1, is_last = 1;
+  const int32_t* left = nullptr;  // device, (m+1) x {H,E}
+  int32_t* right = nullptr;       // device, (m+1) x {H,E}
+  int64_t chunk_rows = 0;
+  sa_stripe_event_fn on_event = nullptr;
+  void* user = nullptr;
+};
 
-  // border chains, literally as the reference builds them (host, O(m+n))
-  std::vector<int> rowb((size_t)n + 1, 0), colb((size_t)m + 1, 0);
-  if (kind == KIND_NW) {
-    for (int j = 1; j <= n; ++j) rowb[j] = (j == 1) ? add_gap(rowb[0], sc->gap_open) : add_gap(rowb[j - 1], sc->gap_extend);  // main.cpp:719-725
-    int fprev = kNeg;
-    for (int i = 1; i <= m; ++i) {  // main.cpp:601-606
-      const int fo = add_gap(colb[i - 1], sc->gap_open), fe = add_gap(fprev, sc->gap_extend);
-      fprev = std::max(fo, fe);
-      colb[i] = fprev;
-    }
-  }
-  if (m == 0 || n == 0) {
-    border_only_result(kind, m, n, rowb, colb, out);
-    return SA_OK;
-  }
+int check_scoring(sa_ctx* ctx, int kind, const sa_scoring* sc, int64_t m, int64_t n_total) {
+  if (kind == KIND_LCS) return SA_OK;
+  if (!sc || !sc->sub || !sc->idx256 || sc->alpha < 1 || sc->alpha > 32) return fail(ctx, SA_ERR_ARG, "bad scoring");
+  if (!(std::fabs(sc->gap_open) <= 1e6) || !(std::fabs(sc->gap_extend) <= 1e6)) return fail(ctx, SA_ERR_ARG, "gap penalty out of range");
+  const double worst = ((double)m + n_total + 2) * std::max({std::fabs(sc->gap_open) + 1, std::fabs(sc->gap_extend) + 1, 128.0});
+  if (worst > 1.0e9) return fail(ctx, SA_ERR_ARG, "score range would overflow int32");
+  return SA_OK;
+}
 
+// Fill of one stripe of columns (the whole matrix when sd == nullptr): uploads, profile, the
+// per-diagonal launch schedule, SW arg-max.  Everything is enqueued on ctx->stream; events
+// ev[0] (start), ev[1] (first fill launch), ev[2] (fill done) are recorded.
+int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, int n, const sa_scoring* sc,
+              const StripeDesc* sd, uint32_t flags, sa_result* out, const std::vector<int>& rowb, const std::vector<int>& colb) {
   HIPCK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
-  const Tuning tun = choose_tuning(ctx, kind, m, n);
+  const bool dump = (flags & SA_FLAG_KEEP_DP) != 0;
+  int go = 0, ge = 0, fo = 0, fe = 0, alpha = 1;
+  if (kind != KIND_LCS) {
+    go = (int)std::floor(sc->gap_open);
+    ge = (int)std::floor(sc->gap_extend);
+    fo = sc->gap_open != std::floor(sc->gap_open);
+    fe = sc->gap_extend != std::floor(sc->gap_extend);
+    alpha = sc->alpha;
+  }
+  const int fl = ((fo || fe) ? FLAG_FRAC : 0) | (dump ? FLAG_DUMP : 0);
+  Tuning tun = choose_tuning(ctx, kind, m, n);
+  if (fl & FLAG_DUMP)
+    tun.K = 1, tun.C = 64;
+  else if (fl & FLAG_FRAC)
+    tun.K = 2;
   const int K = tun.K, C = tun.C;
   const int PW = (K <= 4) ? 1 : K / 4;
   const int S = (m + 64 * K - 1) / (64 * K);
@@ -245,11 +253,12 @@ int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t
   const size_t rows_pad = (size_t)S * 64 * K;
   out->rows_per_lane = K;
   out->tile_steps = C;
+  const bool first = !sd || sd->is_first;
 
   int rc;
   if ((rc = ensure(ctx, ctx->xenc, rows_pad + 64))) return rc;
   if ((rc = ensure(ctx, ctx->yenc, (size_t)Tend + 256))) return rc;
-  if ((rc = ensure(ctx, ctx->colb, (rows_pad + 1) * 4))) return rc;
+  if (first && (rc = ensure(ctx, ctx->lbuf, ((size_t)m + 1) * 8))) return rc;
   if ((rc = ensure(ctx, ctx->bot, (size_t)4 * NP * 4))) return rc;
   if ((rc = ensure(ctx, ctx->state, (size_t)S * NF * 64 * 4))) return rc;
   if ((rc = ensure(ctx, ctx->small, 256))) return rc;
@@ -259,6 +268,7 @@ int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t
     if ((rc = ensure(ctx, ctx->sub, 32 * 32))) return rc;
   }
   if (kind == KIND_SW && (rc = ensure(ctx, ctx->rowbest, (size_t)2 * m * 4))) return rc;
+  if (dump && (rc = ensure(ctx, ctx->dpbuf, ((size_t)m + 1) * ((size_t)n + 1) * 4))) return rc;
   const size_t trace_bytes = (size_t)S * W * 64 * K * 4;
   if ((rc = ensure(ctx, ctx->trace, trace_bytes))) return rc;
 
@@ -271,14 +281,29 @@ int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t
     for (int i = 0; i < m; ++i) xe[i] = sc->idx256[x[i]];
     for (int j = 0; j < n; ++j) ye[j] = sc->idx256[y[j]];
   }
-  std::vector<int> colpad(rows_pad + 1, 0);
-  memcpy(colpad.data(), colb.data(), ((size_t)m + 1) * 4);
-  for (size_t i = (size_t)m + 1; i <= rows_pad; ++i) colpad[i] = colb[m];
+  const int e_border = (kind == KIND_NW) ? kNeg : 0;  // E[i][0]: main.cpp:619 / :1105
+  std::vector<int> lbh;
+  if (first) {
+    lbh.resize(((size_t)m + 1) * 2);
+    for (int i = 0; i <= m; ++i) {
+      lbh[2 * (size_t)i] = colb[i];
+      lbh[2 * (size_t)i + 1] = e_border;
+    }
+  }
 
   HIPCK(ctx, hipEventRecord(ctx->ev[0], st));
   HIPCK(ctx, hipMemcpyAsync(ctx->xenc.p, xe.data(), xe.size(), hipMemcpyHostToDevice, st));
   HIPCK(ctx, hipMemcpyAsync(ctx->yenc.p, ye.data(), ye.size(), hipMemcpyHostToDevice, st));
-  HIPCK(ctx, hipMemcpyAsync(ctx->colb.p, colpad.data(), colpad.size() * 4, hipMemcpyHostToDevice, st));
+  const int2* lb;
+  if (first) {
+    HIPCK(ctx, hipMemcpyAsync(ctx->lbuf.p, lbh.data(), lbh.size() * 4, hipMemcpyHostToDevice, st));
+    lb = (const int2*)ctx->lbuf.p;
+  } else {
+    // entry 0 of the caller's left border is the matrix' row 0 at this stripe's left edge
+    const int corner[2] = {rowb[0], e_border};
+    HIPCK(ctx, hipMemcpyAsync((void*)sd->left, corner, 8, hipMemcpyHostToDevice, st));
+    lb = (const int2*)sd->left;
+  }
   int* botH = (int*)ctx->bot.p;
   int* botF = botH + (size_t)2 * NP;
   // strip 0 reads ring buffer 1: row 0 of the matrix, H[0][j] at p = j + 63
@@ -286,9 +311,8 @@ int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t
   HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)botF, kind == KIND_NW ? kNeg : 0, (size_t)2 * NP, st));
   if (kind == KIND_NW) HIPCK(ctx, hipMemcpyAsync(botH + NP + 64, rowb.data() + 1, (size_t)n * 4, hipMemcpyHostToDevice, st));
   HIPCK(ctx, hipMemsetAsync(ctx->small.p, 0, 256, st));
-  int* d_score = (int*)ctx->small.p;                                         // [0]   NW/LCS score / SW best
+  int* d_score = (int*)ctx->small.p;                                           // [0]   NW/LCS score / SW best
   unsigned long long* d_pos = (unsigned long long*)((char*)ctx->small.p + 8);  // [8]   SW end cell
-  long long* d_hdr = (long long*)((char*)ctx->small.p + 64);                 // [64]  traceback header
   if (kind == KIND_SW) HIPCK(ctx, hipMemsetAsync(d_pos, 0xff, 8, st));
   if (kind != KIND_LCS) {
     HIPCK(ctx, hipMemcpyAsync(ctx->sub.p, sc->sub, (size_t)alpha * alpha, hipMemcpyHostToDevice, st));
@@ -303,12 +327,16 @@ int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t
   a.W = W;
   a.go = go;
   a.ge = ge;
+  a.fo = fo;
+  a.fe = fe;
   a.alpha = alpha;
   a.NP = NP;
   a.yenc = (const uint8_t*)ctx->yenc.p;
   a.prof = (const uint32_t*)ctx->prof.p;
   a.xpad = (const uint8_t*)ctx->xenc.p;
-  a.colb = (const int*)ctx->colb.p;
+  a.lb = lb;
+  a.rb = (sd && !sd->is_last) ? (int2*)sd->right : nullptr;
+  a.dp = dump ? (int*)ctx->dpbuf.p : nullptr;
   a.botH = botH;
   a.botF = botF;
   a.state = (int*)ctx->state.p;
@@ -321,22 +349,44 @@ int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t
   auto f_lo = [&](int s) { return (long long)s + (64LL * s) / C; };
   auto f_hi = [&](int s) { return (long long)s + (64LL * s + n + 62) / C; };
   const long long dmax = f_hi(S - 1);
+  // column stripes: border chunk k = matrix rows k*R+1 .. min(m,(k+1)*R)
+  const bool ev_in = sd && !sd->is_first && sd->on_event;
+  const bool ev_out = sd && !sd->is_last && sd->on_event;
+  const int64_t R = sd ? std::max<int64_t>(sd->chunk_rows, 1) : 0;
+  const int64_t n_chunks = sd ? (m + R - 1) / R : 0;
+  int64_t chunks_in = 0, chunks_out = 0;
   int slo = 0, shi = -1, launches = 0;
   HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
   for (long long d = 0; d <= dmax; ++d) {
     while (shi + 1 < S && f_lo(shi + 1) <= d) ++shi;
     while (slo < S && f_hi(slo) < d) ++slo;
     if (slo > shi) continue;
+    if (ev_in) {  // rows 1 .. (shi+1)*64K must have arrived before this launch
+      const int64_t need_rows = std::min<int64_t>(m, (int64_t)(shi + 1) * 64 * K);
+      while (chunks_in < n_chunks && chunks_in * R < need_rows) {
+        if (sd->on_event(sd->user, SA_EV_NEED_LEFT, chunks_in)) return fail(ctx, SA_ERR_ARG, "stripe callback failed (need chunk %lld)", (long long)chunks_in);
+        ++chunks_in;
+      }
+    }
     a.d = (int)d;
     a.s_lo = slo;
     const dim3 grid(shi - slo + 1);
     if (kind == KIND_NW)
-      launch_fill<KIND_NW>(K, grid, lds, st, a);
+      launch_fill<KIND_NW>(K, fl, grid, lds, st, a);
     else if (kind == KIND_SW)
-      launch_fill<KIND_SW>(K, grid, lds, st, a);
+      launch_fill<KIND_SW>(K, fl, grid, lds, st, a);
     else
-      launch_fill<KIND_LCS>(K, grid, lds, st, a);
+      launch_fill<KIND_LCS>(K, fl & FLAG_DUMP, grid, lds, st, a);
     ++launches;
+    if (ev_out) {  // strips with f_hi(s) <= d are complete after this launch
+      int done = slo;
+      while (done < S && f_hi(done) <= d) ++done;
+      const int64_t rows_done = std::min<int64_t>(m, (int64_t)done * 64 * K);
+      while (chunks_out < n_chunks && std::min<int64_t>(m, (chunks_out + 1) * R) <= rows_done) {
+        if (sd->on_event(sd->user, SA_EV_RIGHT_READY, chunks_out)) return fail(ctx, SA_ERR_ARG, "stripe callback failed (ready chunk %lld)", (long long)chunks_out);
+        ++chunks_out;
+      }
+    }
   }
   HIPCK(ctx, hipGetLastError());
   out->n_launches = launches;
@@ -346,22 +396,40 @@ int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t
     hipLaunchKernelGGL(sw_reduce_pos, dim3(rb), dim3(256), 0, st, a.rowbest, a.rowbestc, m, d_score, d_pos);
   }
   HIPCK(ctx, hipEventRecord(ctx->ev[2], st));
+  ctx->last.valid = 1;
+  ctx->last.kind = kind;
+  ctx->last.m = m;
+  ctx->last.n = n;
+  ctx->last.K = K;
+  ctx->last.W = W;
+  ctx->last.first_stripe = first ? 1 : 0;
+  return SA_OK;
+}
 
+// Traceback over the codes of the last fill + D2H of score / end cell / op list.  Synchronises.
+int traceback_impl(sa_ctx* ctx, int start_i, int start_j, bool want_tb, sa_result* out) {
+  hipStream_t st = ctx->stream;
+  const int kind = ctx->last.kind, m = ctx->last.m, n = ctx->last.n;
+  int* d_score = (int*)ctx->small.p;
+  unsigned long long* d_pos = (unsigned long long*)((char*)ctx->small.p + 8);
+  long long* d_hdr = (long long*)((char*)ctx->small.p + 64);
   struct {
     int score;
     int pad;
     unsigned long long pos;
   } h_sc{};
   long long h_hdr[5] = {0, 0, 0, 0, 0};
-  const bool want_tb = !(flags & SA_FLAG_NO_TRACEBACK);
   if (want_tb) {
     TraceArgs t{};
     t.kind = kind;
     t.m = m;
     t.n = n;
-    t.K = K;
-    t.W = W;
-    t.trace = a.trace;
+    t.K = ctx->last.K;
+    t.W = ctx->last.W;
+    t.start_i = start_i;
+    t.start_j = start_j;
+    t.stop_at_col0 = ctx->last.first_stripe ? 0 : 1;
+    t.trace = (const uint32_t*)ctx->trace.p;
     t.sw_best = d_score;
     t.sw_pos = d_pos;
     t.ops = (uint8_t*)ctx->ops.p;
@@ -379,14 +447,6 @@ int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t
   }
   HIPCK(ctx, hipEventRecord(ctx->ev[3], st));
   HIPCK(ctx, hipEventSynchronize(ctx->ev[3]));
-  float t01 = 0, t12 = 0, t23 = 0;
-  HIPCK(ctx, hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]));
-  HIPCK(ctx, hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]));
-  HIPCK(ctx, hipEventElapsedTime(&t23, ctx->ev[2], ctx->ev[3]));
-  out->fill_ms = t01 + t12;
-  out->kernel_fill_ms = t12;
-  out->traceback_ms = t23;
-
   out->score = h_sc.score;
   if (kind == KIND_SW) {
     if (h_sc.score > 0) {
@@ -396,8 +456,8 @@ int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t
     out->start_i = out->end_i;
     out->start_j = out->end_j;
   } else {
-    out->end_i = m;
-    out->end_j = n;
+    out->end_i = start_i >= 0 ? start_i : m;
+    out->end_j = start_i >= 0 ? start_j : n;
   }
   if (want_tb) {
     out->n_ops = h_hdr[0];
@@ -407,6 +467,129 @@ int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t
   return SA_OK;
 }
 
+// The two O(m+n) border chains, literally as the reference builds them (host):
+// row 0 main.cpp:719-725, column 0 main.cpp:601-606.  SW / LCS borders are zero.
+void border_chains(int kind, int64_t m, int64_t n, const sa_scoring* sc, std::vector<int>& rowb, std::vector<int>& colb) {
+  rowb.assign((size_t)n + 1, 0);
+  colb.assign((size_t)m + 1, 0);
+  if (kind != KIND_NW) return;
+  for (int64_t j = 1; j <= n; ++j) rowb[j] = (j == 1) ? add_gap(rowb[0], sc->gap_open) : add_gap(rowb[j - 1], sc->gap_extend);
+  int fprev = kNeg;
+  for (int64_t i = 1; i <= m; ++i) {
+    const int fo = add_gap(colb[i - 1], sc->gap_open), fe = add_gap(fprev, sc->gap_extend);
+    fprev = std::max(fo, fe);
+    colb[i] = fprev;
+  }
+}
+
+int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t* y, int64_t n64,
+             const sa_scoring* sc, uint32_t flags, sa_result* out) {
+  if (!ctx) return SA_ERR_ARG;
+  if (!out) return fail(ctx, SA_ERR_ARG, "out is NULL");
+  memset(out, 0, sizeof *out);
+  if (m64 < 0 || n64 < 0 || (m64 > 0 && !x) || (n64 > 0 && !y)) return fail(ctx, SA_ERR_ARG, "bad sequence arguments");
+  if (m64 > 0x7ff00000LL || n64 > 0x7ff00000LL) return fail(ctx, SA_ERR_ARG, "sequence longer than int32 indexing (reference Q7)");
+  const int m = (int)m64, n = (int)n64;
+  int rc = check_scoring(ctx, kind, sc, m, n);
+  if (rc) return rc;
+  if (kind != KIND_LCS && first_invalid_pair(x, m, y, n, sc->idx256, &out->bad_x, &out->bad_y))
+    return fail(ctx, SA_ERR_INVALID_CODE, "invalid residue pair %c,%c", out->bad_x, out->bad_y);
+  const bool dump = (flags & SA_FLAG_KEEP_DP) != 0;
+  if (dump && ((double)m + 1) * ((double)n + 1) > 1.5e9)
+    return fail(ctx, SA_ERR_NOMEM, "SA_FLAG_KEEP_DP: a %d x %d int32 matrix is beyond the 6 GB dump limit", m + 1, n + 1);
+
+  std::vector<int> rowb, colb;
+  border_chains(kind, m, n, sc, rowb, colb);
+  if (dump) {
+    out->dp = (int32_t*)calloc(((size_t)m + 1) * ((size_t)n + 1), 4);
+    if (!out->dp) return fail(ctx, SA_ERR_NOMEM, "host malloc of the dp matrix failed");
+  }
+  if (m == 0 || n == 0) {
+    border_only_result(kind, m, n, rowb, colb, out);
+  } else {
+    if ((rc = fill_impl(ctx, kind, x, m, y, n, sc, nullptr, flags, out, rowb, colb))) return rc;
+    if (dump) HIPCK(ctx, hipMemcpyAsync(out->dp, ctx->dpbuf.p, ((size_t)m + 1) * ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if ((rc = traceback_impl(ctx, -1, -1, !(flags & SA_FLAG_NO_TRACEBACK), out))) return rc;
+    float t01 = 0, t12 = 0, t23 = 0;
+    HIPCK(ctx, hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]));
+    HIPCK(ctx, hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]));
+    HIPCK(ctx, hipEventElapsedTime(&t23, ctx->ev[2], ctx->ev[3]));
+    out->fill_ms = t01 + t12;
+    out->kernel_fill_ms = t12;
+    out->traceback_ms = t23;
+  }
+  if (dump) {  // borders of the dumped matrix (the kernel writes interior cells only)
+    const size_t w = (size_t)n + 1;
+    for (int j = 0; j <= n; ++j) out->dp[j] = rowb[j];
+    for (int i = 0; i <= m; ++i) out->dp[(size_t)i * w] = colb[i];
+  }
+  return SA_OK;
+}
+
+// ---- column stripes (multi-GPU, one process per GPU; the caller moves the borders) ----
+int run_stripe_fill(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t* y, int64_t n64, const sa_scoring* sc,
+                    const sa_stripe_desc* d, sa_result* out) {
+  if (!ctx) return SA_ERR_ARG;
+  if (!out || !d) return fail(ctx, SA_ERR_ARG, "NULL argument");
+  memset(out, 0, sizeof *out);
+  if (kind == KIND_SW) return fail(ctx, SA_ERR_UNSUPPORTED, "column stripes are implemented for NW and LCS");
+  if (m64 <= 0 || n64 <= 0 || !x || !y) return fail(ctx, SA_ERR_ARG, "a stripe needs m > 0 and n > 0");
+  if (m64 > 0x7ff00000LL || d->n_total > 0x7ff00000LL || d->col_begin < 0 || d->col_begin + n64 > d->n_total)
+    return fail(ctx, SA_ERR_ARG, "bad stripe geometry");
+  if ((!d->is_first && !d->left) || (!d->is_last && !d->right) || d->chunk_rows <= 0) return fail(ctx, SA_ERR_ARG, "bad stripe borders");
+  const int m = (int)m64, n = (int)n64;
+  int rc = check_scoring(ctx, kind, sc, m, d->n_total);
+  if (rc) return rc;
+  if (kind != KIND_LCS) {
+    if (sc->gap_open != std::floor(sc->gap_open) || sc->gap_extend != std::floor(sc->gap_extend))
+      return fail(ctx, SA_ERR_UNSUPPORTED, "fractional gap penalties are not implemented for column stripes");
+    if (first_invalid_pair(x, m, y, n, sc->idx256, &out->bad_x, &out->bad_y))
+      return fail(ctx, SA_ERR_INVALID_CODE, "invalid residue pair %c,%c", out->bad_x, out->bad_y);
+  }
+  // row 0 of this stripe = the global row-0 chain from column col_begin on
+  std::vector<int> rowb_all, colb;
+  border_chains(kind, d->is_first ? m : 0, d->col_begin + n, sc, rowb_all, colb);
+  std::vector<int> rowb(rowb_all.begin() + d->col_begin, rowb_all.end());
+  StripeDesc sd;
+  sd.n_total = d->n_total;
+  sd.col_begin = d->col_begin;
+  sd.is_first = d->is_first;
+  sd.is_last = d->is_last;
+  sd.left = d->left;
+  sd.right = d->right;
+  sd.chunk_rows = d->chunk_rows;
+  sd.on_event = d->on_event;
+  sd.user = d->user;
+  if ((rc = fill_impl(ctx, kind, x, m, y, n, sc, &sd, 0, out, rowb, colb))) return rc;
+  int h_score = 0;
+  HIPCK(ctx, hipMemcpyAsync(&h_score, ctx->small.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCK(ctx, hipStreamSynchronize(ctx->stream));
+  float t01 = 0, t12 = 0;
+  HIPCK(ctx, hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]));
+  HIPCK(ctx, hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]));
+  out->fill_ms = t01 + t12;
+  out->kernel_fill_ms = t12;
+  out->score = h_score;  // meaningful on the last stripe only
+  out->end_i = m;
+  out->end_j = n;
+  return SA_OK;
+}
+
+int run_stripe_traceback(sa_ctx* ctx, int64_t start_i, int64_t start_j, sa_result* out) {
+  if (!ctx) return SA_ERR_ARG;
+  if (!out) return fail(ctx, SA_ERR_ARG, "out is NULL");
+  memset(out, 0, sizeof *out);
+  if (!ctx->last.valid) return fail(ctx, SA_ERR_ARG, "no fill to trace back");
+  if (start_i < 0 || start_i > ctx->last.m || start_j < 0 || start_j > ctx->last.n) return fail(ctx, SA_ERR_ARG, "start cell outside the stripe");
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  HIPCK(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+  int rc = traceback_impl(ctx, (int)start_i, (int)start_j, true, out);
+  if (rc) return rc;
+  float t23 = 0;
+  HIPCK(ctx, hipEventElapsedTime(&t23, ctx->ev[2], ctx->ev[3]));
+  out->traceback_ms = t23;
+  return SA_OK;
+}
 
 template <int K>
 void launch_batch(hipStream_t st, int count, int alpha, const BatchArgs& a) {
@@ -640,7 +823,7 @@ int sa_release_workspace(sa_ctx* c) {
   if (!c) return SA_ERR_ARG;
   (void)hipSetDevice(c->device);
   for (Buf* b : {&c->xenc, &c->yenc, &c->prof, &c->sub, &c->colb, &c->bot, &c->state, &c->trace, &c->rowbest, &c->small,
-                 &c->ops, &c->b_seq, &c->b_desc, &c->b_out})
+                 &c->ops, &c->b_seq, &c->b_desc, &c->b_out, &c->lbuf, &c->dpbuf})
     release(*b);
   return SA_OK;
 }
@@ -673,6 +856,16 @@ int sa_sw(sa_ctx* ctx, const uint8_t* x, int64_t m, const uint8_t* y, int64_t n,
 
 int sa_lcs(sa_ctx* ctx, const uint8_t* x, int64_t m, const uint8_t* y, int64_t n, uint32_t flags, sa_result* out) {
   return run_pair(ctx, KIND_LCS, x, m, y, n, nullptr, flags, out);
+}
+
+int sa_stripe_fill(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m, const uint8_t* y_stripe, int64_t n_stripe,
+                   const sa_scoring* sc, const sa_stripe_desc* desc, sa_result* out) {
+  if (kind != SA_KIND_NW && kind != SA_KIND_LCS && kind != SA_KIND_SW) return fail(ctx, SA_ERR_ARG, "bad kind");
+  return run_stripe_fill(ctx, kind, x, m, y_stripe, n_stripe, sc, desc, out);
+}
+
+int sa_stripe_traceback(sa_ctx* ctx, int64_t start_i, int64_t start_j, sa_result* out) {
+  return run_stripe_traceback(ctx, start_i, start_j, out);
 }
 
 int sa_sw_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x, const int64_t* off_y,

@@ -68,6 +68,26 @@ class _Result(C.Structure):
     ]
 
 
+STRIPE_EVENT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int64)
+SA_EV_NEED_LEFT = 0
+SA_EV_RIGHT_READY = 1
+KINDS = {"nw": 0, "sw": 1, "lcs": 2}
+
+
+class _StripeDesc(C.Structure):
+    _fields_ = [
+        ("n_total", C.c_int64),
+        ("col_begin", C.c_int64),
+        ("is_first", C.c_int32),
+        ("is_last", C.c_int32),
+        ("left", C.c_void_p),
+        ("right", C.c_void_p),
+        ("chunk_rows", C.c_int64),
+        ("on_event", STRIPE_EVENT_FN),
+        ("user", C.c_void_p),
+    ]
+
+
 @dataclass
 class AlignResult:
     score: int
@@ -121,7 +141,11 @@ def load_library() -> C.CDLL:
     L.sa_sw.argtypes = pair
     L.sa_lcs.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_uint32, C.POINTER(_Result)]
     L.sa_sw_batch.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, C.POINTER(_Scoring), vp, vp, vp, C.POINTER(C.c_float)]
-    for f in ("sa_set_stream", "sa_set_tuning", "sa_release_workspace", "sa_nw", "sa_sw", "sa_lcs", "sa_sw_batch"):
+    L.sa_stripe_fill.argtypes = [vp, C.c_int, vp, C.c_int64, vp, C.c_int64, C.POINTER(_Scoring), C.POINTER(_StripeDesc),
+                                 C.POINTER(_Result)]
+    L.sa_stripe_traceback.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(_Result)]
+    for f in ("sa_set_stream", "sa_set_tuning", "sa_release_workspace", "sa_nw", "sa_sw", "sa_lcs", "sa_sw_batch",
+              "sa_stripe_fill", "sa_stripe_traceback"):
         getattr(L, f).restype = C.c_int
     _lib = L
     return L
@@ -217,6 +241,42 @@ class Engine:
         if rc:
             raise self._err(rc, r)
         return self._wrap(r, len(x), len(y), bool(flags & SA_FLAG_KEEP_DP))
+
+    # ---- column stripes (one process per GPU; the caller moves the border chunks) ----------
+    def stripe_fill(self, kind, x, y_stripe, n_total, col_begin, is_first, is_last, left_ptr, right_ptr, chunk_rows,
+                    on_event, mode="dna", gap_open=-5.0, gap_extend=-1.0) -> AlignResult:
+        """on_event(event, chunk) -> None is called while the fill is being enqueued (see
+        include/seqalign_hip.h); left_ptr / right_ptr are device addresses of int32[m+1][2]."""
+        x, y = _u8(x), _u8(y_stripe)
+        sc, keep = self._scoring(mode, gap_open, gap_extend)
+        err = []
+
+        def _cb(_user, event, chunk):
+            try:
+                on_event(event, chunk)
+                return 0
+            except BaseException as e:  # never let an exception cross the C frame
+                err.append(e)
+                return 1
+
+        cb = STRIPE_EVENT_FN(_cb)
+        d = _StripeDesc(int(n_total), int(col_begin), int(is_first), int(is_last), left_ptr, right_ptr, int(chunk_rows), cb, None)
+        r = _Result()
+        rc = self.lib.sa_stripe_fill(self.ctx, KINDS[kind], x.ctypes.data, len(x), y.ctypes.data, len(y), C.byref(sc),
+                                     C.byref(d), C.byref(r))
+        del keep
+        if err:
+            raise err[0]
+        if rc:
+            raise self._err(rc, r)
+        return self._wrap(r, len(x), len(y), False)
+
+    def stripe_traceback(self, start_i, start_j) -> AlignResult:
+        r = _Result()
+        rc = self.lib.sa_stripe_traceback(self.ctx, int(start_i), int(start_j), C.byref(r))
+        if rc:
+            raise self._err(rc, r)
+        return self._wrap(r, 0, 0, False)
 
     def sw_batch(self, seqs, off_x, len_x, off_y, len_y, mode="protein", gap_open=-5.0, gap_extend=-1.0):
         seqs = _u8(seqs)

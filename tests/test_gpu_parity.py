@@ -137,3 +137,54 @@ def test_medium_dna_20k(engine, oracle):
     ol = oracle.lcs(x, y, packed=True)
     gl = engine.lcs(x, y)
     assert gl.score == ol.score and np.array_equal(gl.ops, ol.ops)
+
+
+@pytest.mark.parametrize("go,ge", [(-5.5, -0.5), (-4.25, -1.75), (-0.5, -0.5), (-7.9, -0.1), (-5.0, -0.5), (-5.5, -1.0)])
+@pytest.mark.parametrize("kind", ["nw", "sw"])
+def test_fractional_gap_penalties(engine, oracle, kind, go, ge):
+    """Quirk Q3: int + double truncated per operation (main.cpp:603); the GPU emulates the
+    truncation in integer arithmetic."""
+    rng = np.random.default_rng(29)
+    x = rand_seq(rng, 900, DNA)
+    y = mutate(rng, x, DNA, 0.1, 0.05, 0.05)
+    check(kind, engine, oracle, x, y, "dna", go, ge)
+    xp = rand_seq(rng, 333, PROT20)
+    yp = mutate(rng, xp, PROT20, 0.3, 0.05, 0.05)
+    check(kind, engine, oracle, xp, yp, "protein", go, ge)
+    check(kind, engine, oracle, rand_seq(rng, 200, PROT24), rand_seq(rng, 300, PROT24), "protein", go, ge)
+
+
+def test_fractional_gap_golden_scores(engine):
+    import json
+    from pathlib import Path
+
+    cases = json.loads((Path(__file__).parent / "golden" / "random_pairs.json").read_text())
+    n = 0
+    for c in cases:
+        if c["go"] is None or float(c["go"]).is_integer() and float(c["ge"]).is_integer():
+            continue
+        import re
+        want = int(re.search(r'"score":\s*(-?\d+)', c["files"]["global_stats.json"]).group(1))
+        assert engine.nw(c["x"], c["y"], c["mode"], c["go"], c["ge"]).score == want, c["id"]
+        want = int(re.search(r'"score":\s*(-?\d+)', c["files"]["local_stats.json"]).group(1))
+        assert engine.sw(c["x"], c["y"], c["mode"], c["go"], c["ge"]).score == want, c["id"]
+        n += 1
+    assert n >= 8
+
+
+@pytest.mark.parametrize("kind", ["nw", "sw", "lcs"])
+def test_keep_dp_matrix(engine, oracle, kind):
+    """SA_FLAG_KEEP_DP: the full S / L matrix the reference dumps with --binary/--txt."""
+    rng = np.random.default_rng(31)
+    for (m, n, mode, go, ge) in [(1, 1, "dna", -5.0, -1.0), (37, 91, "dna", -5.0, -1.0), (300, 257, "protein", -5.0, -1.0),
+                                 (130, 64, "dna", -5.5, -0.5), (0, 5, "dna", -5.0, -1.0), (5, 0, "dna", -5.0, -1.0)]:
+        alpha = DNA if mode == "dna" else PROT20
+        x, y = rand_seq(rng, m, alpha), rand_seq(rng, n, alpha)
+        if kind == "lcs":
+            g, o = engine.lcs(x, y, flags=1), oracle.lcs(x, y, keep_dp=True)
+        else:
+            g = getattr(engine, kind)(x, y, mode, go, ge, flags=1)
+            o = getattr(oracle, kind)(x, y, mode, go, ge, keep_dp=True)
+        assert g.score == o.score and np.array_equal(g.ops, o.ops)
+        assert g.dp is not None and g.dp.shape == (m + 1, n + 1)
+        assert np.array_equal(g.dp, o.dp), f"{kind} {m}x{n}"
