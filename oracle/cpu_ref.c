@@ -760,3 +760,148 @@ int orc_nw_banded(const uint8_t* x, int64_t m, const uint8_t* y, int64_t n, int 
   free(rows);
   return rc;
 }
+
+/* -------------------------------------------------------------- stripes --- */
+
+struct orc_stripe {
+  int kind, is_first;
+  int64_t m, n;
+  uint8_t* T; /* (m+1) x (n+1) direction codes 0/1/2 */
+};
+
+/* One column stripe of the NW / LCS matrix, row by row, with the left border taken from `left`
+ * (values of the column just left of the stripe) and the stripe's last column written to
+ * `right`.  Same recurrences as nw_row / orc_lcs; only the source of column 0 differs. */
+int orc_stripe_fill(int kind, const uint8_t* x, int64_t m, const uint8_t* y, int64_t n, int mode, double go, double ge,
+                    int64_t n_total, int64_t col_begin, int is_first, int is_last, int32_t* left, int32_t* right,
+                    int64_t chunk_rows, orc_stripe_event_fn on_event, void* user, orc_stripe** handle, int64_t* score) {
+  (void)n_total;
+  scoring sc = {mode, go, ge, 0, 0, 0};
+  size_t w = (size_t)n + 1;
+  orc_stripe* h = (orc_stripe*)calloc(1, sizeof *h);
+  h->kind = kind;
+  h->is_first = is_first;
+  h->m = m;
+  h->n = n;
+  h->T = (uint8_t*)calloc((size_t)(m + 1) * w, 1);
+  int* rows = (int*)malloc(6 * w * sizeof(int));
+  int *pS = rows, *pF = rows + w, *pE = rows + 2 * w, *cS = rows + 3 * w, *cF = rows + 4 * w, *cE = rows + 5 * w;
+  /* row 0: the global chain evaluated up to this stripe */
+  int s0 = 0, e0 = NEG_INF;
+  for (int64_t j = 1; j <= col_begin + n; ++j) {
+    if (kind == 0) {
+      e0 = (j == 1) ? add_gap(s0, go) : add_gap(e0, ge);
+      s0 = e0;
+    }
+    if (j >= col_begin) {
+      pS[j - col_begin] = s0;
+      pE[j - col_begin] = e0;
+      pF[j - col_begin] = NEG_INF;
+      if (j > col_begin) h->T[j - col_begin] = 1;
+    }
+  }
+  if (col_begin == 0) {
+    pS[0] = 0;
+    pE[0] = pF[0] = NEG_INF;
+  }
+  if (kind != 0)
+    for (size_t j = 0; j < w; ++j) pS[j] = pE[j] = pF[j] = 0;
+  int64_t chunks_in = 0, chunks_out = 0, n_chunks = (m + chunk_rows - 1) / chunk_rows;
+  for (int64_t i = 1; i <= m; ++i) {
+    if (!is_first && on_event && chunks_in < n_chunks && (i - 1) / chunk_rows >= chunks_in) {
+      if (on_event(user, 0, chunks_in)) return -9;
+      ++chunks_in;
+    }
+    uint8_t* t = h->T + (size_t)i * w;
+    if (is_first) {
+      if (kind == 0) {
+        int fo = add_gap(pS[0], go), fe = add_gap(pF[0], ge);
+        cF[0] = imax(fo, fe);
+        cS[0] = cF[0];
+        cE[0] = NEG_INF;
+      } else {
+        cS[0] = cE[0] = cF[0] = 0;
+      }
+      t[0] = 2;
+    } else {
+      cS[0] = left[2 * i];
+      cE[0] = left[2 * i + 1];
+      cF[0] = NEG_INF; /* never read: F of column 0 feeds nothing to the right */
+    }
+    for (int64_t j = 1; j <= n; ++j) {
+      if (kind == 0) {
+        int f_open = add_gap(pS[j], go), f_ext = add_gap(pF[j], ge);
+        cF[j] = imax(f_open, f_ext);
+        int e_open = add_gap(cS[j - 1], go), e_ext = add_gap(cE[j - 1], ge);
+        cE[j] = imax(e_open, e_ext);
+        int sg = sigma(&sc, x[i - 1], y[j - 1]);
+        int mv = pS[j - 1] + sg;
+        if (mv >= cE[j] && mv >= cF[j]) {
+          cS[j] = mv;
+          t[j] = 0;
+        } else if (cE[j] >= cF[j]) {
+          cS[j] = cE[j];
+          t[j] = 1;
+        } else {
+          cS[j] = cF[j];
+          t[j] = 2;
+        }
+      } else {
+        if (x[i - 1] == y[j - 1]) {
+          cS[j] = pS[j - 1] + 1;
+          t[j] = 0;
+        } else if (pS[j] >= cS[j - 1]) {
+          cS[j] = pS[j];
+          t[j] = 2;
+        } else {
+          cS[j] = cS[j - 1];
+          t[j] = 1;
+        }
+        cE[j] = cF[j] = 0;
+      }
+    }
+    if (!is_last) {
+      right[2 * i] = cS[n];
+      right[2 * i + 1] = cE[n];
+      if (on_event && (i % chunk_rows == 0 || i == m)) {
+        if (on_event(user, 1, chunks_out)) return -9;
+        ++chunks_out;
+      }
+    }
+    int* tt;
+    tt = pS, pS = cS, cS = tt;
+    tt = pF, pF = cF, cF = tt;
+    tt = pE, pE = cE, cE = tt;
+  }
+  *score = pS[n];
+  free(rows);
+  *handle = h;
+  return sc.bad ? ORC_ERR_INVALID_CODE : ORC_OK;
+}
+
+int orc_stripe_traceback(orc_stripe* h, int64_t ci, int64_t cj, orc_result* out) {
+  memset(out, 0, sizeof *out);
+  size_t w = (size_t)h->n + 1;
+  int64_t cap = 0;
+  out->end_i = ci;
+  out->end_j = cj;
+  while (h->is_first ? (ci > 0 || cj > 0) : (cj > 0)) {
+    unsigned c = (ci == 0) ? 1u : (cj == 0 ? 2u : h->T[(size_t)ci * w + cj]);
+    ops_push(&out->ops, &out->n_ops, &cap, (uint8_t)c);
+    if (c == 0)
+      --ci, --cj;
+    else if (c == 1)
+      --cj;
+    else
+      --ci;
+  }
+  out->start_i = ci;
+  out->start_j = cj;
+  return ORC_OK;
+}
+
+void orc_stripe_free(orc_stripe* h) {
+  if (!h) return;
+  free(h->T);
+  free(h);
+}

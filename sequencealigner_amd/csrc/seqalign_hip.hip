@@ -100,7 +100,9 @@ struct Tuning {
 // Pick rows-per-lane K and tile length C by a small cost model: a wave issues one VALU
 // instruction per 4 cycles and one wave saturates its SIMD (measured, profiles/), so the time
 // is max(critical path over launches, total work / 1024 SIMDs).
-Tuning choose_tuning(const sa_ctx* ctx, int kind, int64_t m, int64_t n) {
+// n_upstream: columns owned by the stripes to the left (multi-GPU): this stripe cannot start
+// before its first strip has crossed them, at one column per step.
+Tuning choose_tuning(const sa_ctx* ctx, int kind, int64_t m, int64_t n, int64_t n_upstream = 0) {
   const double cell = kind == KIND_LCS ? 8.0 : (kind == KIND_SW ? 19.0 : 15.0);
   const double step0 = kind == KIND_LCS ? 9.0 : 13.0;
   const double launch_cycles = 2.5e-6 * 2.4e9;
@@ -113,7 +115,7 @@ Tuning choose_tuning(const sa_ctx* ctx, int kind, int64_t m, int64_t n) {
       const double S = std::ceil((double)m / (64.0 * K));
       const double L = std::ceil((64.0 * S + n + 63) / C) + S;
       const double tile = C * (cell * K + step0) * 4.0 + 3000.0;  // + state/profile load
-      const double crit = L * (tile + launch_cycles);
+      const double crit = L * (tile + launch_cycles) + (double)n_upstream * ((cell * K + step0) * 4.0 + launch_cycles / C);
       const double thr = S * std::ceil((n + 63.0) / C) * tile / 1024.0;
       const double est = std::max(crit, thr) + 0.05 * std::min(crit, thr);
       if (est < best) {
@@ -238,7 +240,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
     alpha = sc->alpha;
   }
   const int fl = ((fo || fe) ? FLAG_FRAC : 0) | (dump ? FLAG_DUMP : 0);
-  Tuning tun = choose_tuning(ctx, kind, m, n);
+  Tuning tun = choose_tuning(ctx, kind, m, n, sd ? sd->col_begin : 0);
   if (fl & FLAG_DUMP)
     tun.K = 1, tun.C = 64;
   else if (fl & FLAG_FRAC)

@@ -1,0 +1,147 @@
+"""One long pair over several GPUs: column stripes, one process per GPU.
+
+Rank g owns the columns [n*g/G, n*(g+1)/G) of the same DP matrix and runs the ordinary
+strip/tile fill on them (sa_stripe_fill).  The only exchange is the stripe's border column,
+(H, E) per matrix row = 8 bytes per row, sent rank g -> g+1 in chunks of `chunk_rows` rows with
+torch.distributed send/recv (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
+tests): nearest-neighbour point-to-point only, no collective on the data path.  The traceback then
+runs right to left, each rank walking its own codes and handing the exit row to its left
+neighbour; rank 0 concatenates the op lists.
+
+The engine is duck-typed (stripe_fill / stripe_traceback / alloc_border) so that the same
+orchestration is exercised on CPU by the tests with an oracle-backed engine.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .engine import SA_EV_NEED_LEFT, AlignResult
+
+
+class GpuStripeEngine:
+    """sa.Engine + torch CUDA tensors for the borders; kernels run on torch's current stream so
+    that they are ordered with the RCCL send/recv torch enqueues."""
+
+    def __init__(self, device_index: int):
+        import torch
+
+        from .engine import Engine
+
+        self.torch = torch
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        self.eng = Engine(device_index)
+        self.eng.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def alloc_border(self, m):
+        return self.torch.zeros((m + 1, 2), dtype=self.torch.int32, device=self.device)
+
+    def small(self, values, dtype=None):
+        return self.torch.tensor(values, dtype=dtype or self.torch.int64, device=self.device)
+
+    def bytes_tensor(self, arr: np.ndarray):
+        return self.torch.from_numpy(np.ascontiguousarray(arr)).to(self.device)
+
+    def empty_bytes(self, n):
+        return self.torch.empty(n, dtype=self.torch.uint8, device=self.device)
+
+    def stripe_fill(self, *a, **kw):
+        return self.eng.stripe_fill(*a, **kw)
+
+    def stripe_traceback(self, i, j):
+        return self.eng.stripe_traceback(i, j)
+
+    def whole(self, kind, x, y, mode, go, ge):
+        return self.eng.lcs(x, y) if kind == "lcs" else getattr(self.eng, kind)(x, y, mode, go, ge)
+
+
+class StripedAligner:
+    def __init__(self, local_rank, rank, world, dist, engine=None, chunk_rows=8192, min_stripe_cols=256):
+        self.rank, self.world, self.dist = rank, world, dist
+        self.engine = engine if engine is not None else GpuStripeEngine(local_rank)
+        self.chunk_rows = int(chunk_rows)
+        self.min_stripe_cols = int(min_stripe_cols)
+
+    def align(self, kind, x, y, mode="dna", gap_open=-5.0, gap_extend=-1.0) -> AlignResult:
+        """Every rank passes the same x and y; every rank returns the score, rank 0 also the
+        complete op list (identical to the single-GPU sa_nw / sa_lcs result)."""
+        if kind not in ("nw", "lcs"):
+            raise ValueError("column stripes are implemented for nw and lcs")
+        E, dist, g, G = self.engine, self.dist, self.rank, self.world
+        x = np.frombuffer(x.encode("latin-1") if isinstance(x, str) else bytes(x), np.uint8) if not isinstance(x, np.ndarray) else x
+        y = np.frombuffer(y.encode("latin-1") if isinstance(y, str) else bytes(y), np.uint8) if not isinstance(y, np.ndarray) else y
+        m, n = len(x), len(y)
+        if G == 1 or m == 0 or n < self.min_stripe_cols * G:
+            return self._on_rank0(kind, x, y, mode, gap_open, gap_extend)
+
+        bounds = [n * k // G for k in range(G + 1)]
+        c0, c1 = bounds[g], bounds[g + 1]
+        ng = c1 - c0
+        first, last = g == 0, g == G - 1
+        left = None if first else E.alloc_border(m)
+        right = None if last else E.alloc_border(m)
+        R = self.chunk_rows
+        sends = []
+
+        def on_event(event, k):
+            lo, hi = k * R + 1, min(m, (k + 1) * R) + 1
+            if event == SA_EV_NEED_LEFT:
+                dist.recv(left[lo:hi], src=g - 1)
+            else:
+                sends.append(dist.isend(right[lo:hi], dst=g + 1))
+
+        res = E.stripe_fill(kind, x, y[c0:c1], n, c0, first, last,
+                            None if first else left.data_ptr(), None if last else right.data_ptr(), R, on_event,
+                            mode, gap_open, gap_extend)
+        for w in sends:
+            w.wait()
+
+        # traceback, right to left: (exit row) travels g+1 -> g
+        if last:
+            si = m
+        else:
+            t = E.small([0])
+            dist.recv(t, src=g + 1)
+            si = int(t.item())
+        tb = E.stripe_traceback(si, ng)
+        if not first:
+            dist.send(E.small([tb.start[0]]), dst=g - 1)
+
+        # op lists to rank 0 (right-most stripe first), score from the last rank
+        score = E.small([res.score if last else 0])
+        dist.broadcast(score, src=G - 1)
+        if g == 0:
+            parts = {0: tb.ops}
+            for src in range(1, G):
+                ln = E.small([0])
+                dist.recv(ln, src=src)
+                buf = E.empty_bytes(int(ln.item()))
+                if int(ln.item()):
+                    dist.recv(buf, src=src)
+                parts[src] = buf.cpu().numpy()
+            ops = np.concatenate([parts[k] for k in range(G - 1, -1, -1)]) if parts else np.zeros(0, np.uint8)
+        else:
+            dist.send(E.small([len(tb.ops)]), dst=0)
+            if len(tb.ops):
+                dist.send(E.bytes_tensor(tb.ops), dst=0)
+            ops = np.zeros(0, np.uint8)
+        out = AlignResult(int(score.item()), (m, n), (0, 0), ops)
+        out.fill_ms, out.kernel_fill_ms, out.traceback_ms = res.fill_ms, res.kernel_fill_ms, tb.traceback_ms
+        out.n_launches, out.rows_per_lane, out.tile_steps = res.n_launches, res.rows_per_lane, res.tile_steps
+        out.extra = {"stripe": (c0, c1), "stripe_ops": len(tb.ops)}
+        return out
+
+    def _on_rank0(self, kind, x, y, mode, go, ge) -> AlignResult:
+        """Inputs too small to stripe: rank 0 aligns, everybody learns the score."""
+        E, dist = self.engine, self.dist
+        if self.rank == 0:
+            r = E.whole(kind, x, y, mode, go, ge)
+            vals = [r.score]
+        else:
+            r = AlignResult(0, (len(x), len(y)), (0, 0), np.zeros(0, np.uint8))
+            vals = [0]
+        if self.world > 1:
+            t = E.small(vals)
+            dist.broadcast(t, src=0)
+            r.score = int(t.item())
+        return r

@@ -1,0 +1,102 @@
+"""GPU: the stripe kernels (border in / border out / stop-at-left-edge traceback) on one device.
+The ranks of a striped run are replayed one after the other in a single process, so the border
+of stripe g is complete before stripe g+1 starts; the exchange protocol itself is covered by
+tests/test_stripes_gloo.py.  The stitched result must equal the single-GPU result bit for bit."""
+import numpy as np
+import pytest
+
+from conftest import DNA, PROT20, mutate, rand_seq
+
+pytestmark = pytest.mark.gpu
+
+
+class DevBuf:
+    """Plain hipMalloc'd border buffer (no torch in this test: the HIP runtime the engine loaded
+    is used directly)."""
+    hip = None
+
+    def __init__(self, nbytes):
+        import ctypes as C
+
+        if DevBuf.hip is None:
+            DevBuf.hip = C.CDLL("libamdhip64.so")
+            DevBuf.hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+            DevBuf.hip.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+            DevBuf.hip.hipFree.argtypes = [C.c_void_p]
+        self.p = C.c_void_p()
+        assert DevBuf.hip.hipMalloc(C.byref(self.p), nbytes) == 0
+        assert DevBuf.hip.hipMemset(self.p, 0, nbytes) == 0
+
+    def data_ptr(self):
+        return self.p.value
+
+    def free(self):
+        DevBuf.hip.hipFree(self.p)
+
+
+def striped(engine, kind, x, y, G, mode, go, ge, chunk_rows):
+    xb = np.frombuffer(x.encode(), np.uint8)
+    yb = np.frombuffer(y.encode(), np.uint8)
+    m, n = len(xb), len(yb)
+    bounds = [n * k // G for k in range(G + 1)]
+    events = []
+    borders = [None] + [DevBuf((m + 1) * 8) for _ in range(G - 1)] + [None]
+    score = None
+    # the trace of stripe g must survive until its traceback: one engine per stripe
+    import sequencealigner_amd as sa
+
+    engs = [engine] + [sa.Engine(0) for _ in range(G - 1)]
+    for g in range(G):
+        left, right = borders[g], borders[g + 1]
+        r = engs[g].stripe_fill(kind, xb, yb[bounds[g]:bounds[g + 1]], n, bounds[g], g == 0, g == G - 1,
+                                None if left is None else left.data_ptr(), None if right is None else right.data_ptr(),
+                                chunk_rows, lambda ev, k, g=g: events.append((g, ev, k)), mode, go, ge)
+        if g == G - 1:
+            score = r.score
+    ops = []
+    si = m
+    for g in range(G - 1, -1, -1):
+        tb = engs[g].stripe_traceback(si, bounds[g + 1] - bounds[g])
+        ops.append(tb.ops)
+        si = tb.start[0]
+        assert tb.start[1] == 0
+    assert si == 0
+    for e in engs[1:]:
+        e.close()
+    for b in borders:
+        if b is not None:
+            b.free()
+    return score, np.concatenate(ops), events
+
+
+@pytest.mark.parametrize("kind", ["nw", "lcs"])
+def test_stripes_equal_single_gpu(engine, oracle, kind):
+    rng = np.random.default_rng(41)
+    for (m, G, K, C, R) in [(700, 2, 1, 64, 100), (3000, 3, 2, 128, 512), (5000, 4, 4, 64, 1000), (2500, 8, 8, 256, 4096)]:
+        x = rand_seq(rng, m, DNA)
+        y = mutate(rng, x, DNA)
+        for e in (engine,):
+            e.set_tuning(K, C)
+        want = oracle.lcs(x, y) if kind == "lcs" else oracle.nw(x, y, "dna")
+        import sequencealigner_amd as sa
+
+        score, ops, events = striped(engine, kind, x, y, G, "dna", -5.0, -1.0, R)
+        assert score == want.score, (kind, m, G)
+        assert np.array_equal(ops, want.ops), (kind, m, G)
+        n_chunks = (m + R - 1) // R
+        for g in range(G):
+            need = [k for (gg, ev, k) in events if gg == g and ev == 0]
+            ready = [k for (gg, ev, k) in events if gg == g and ev == 1]
+            assert need == (list(range(n_chunks)) if g > 0 else [])
+            assert ready == (list(range(n_chunks)) if g < G - 1 else [])
+    engine.set_tuning(0, 0)
+
+
+def test_stripes_protein_and_gaps(engine, oracle):
+    rng = np.random.default_rng(43)
+    x = rand_seq(rng, 1800, PROT20)
+    y = mutate(rng, x, PROT20, 0.2, 0.05, 0.05)
+    for go, ge in ((-5.0, -1.0), (-11.0, -1.0), (-2.0, -2.0)):
+        want = oracle.nw(x, y, "protein", go, ge)
+        score, ops, _ = striped(engine, "nw", x, y, 3, "protein", go, ge, 256)
+        assert score == want.score and np.array_equal(ops, want.ops)
