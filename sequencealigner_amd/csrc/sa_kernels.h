@@ -18,6 +18,13 @@
 // (s,q) depends only on tiles (s-1,q), (s-1,q-1) and (s,q-1), so launch d runs every
 // tile with s+q == d and stream order is the only synchronisation.
 //
+// NW / SW arithmetic is done on TAGGED values: every score v is held as 4*v and the three
+// candidates of a cell carry their identity in the two low bits (M: +2, E: +1, F: +0), so one
+// v_max3 yields both the value and the reference's tie-break (M over E over F, main.cpp:649-671:
+// 4M+2 beats 4E+1 iff M >= E, 4E+1 beats 4F iff E >= F) and the direction code is just the two
+// low bits of the result -- no compares, no selects; v_alignbit shifts it into the trace word.
+// SW adds max(.,3): a zero cell gets tag 3 = the reference's 'X' pointer (main.cpp:1010).
+//
 // Recurrences restate the reference exactly (see DESIGN.md for the proof obligations):
 //   NW  main.cpp:622-672   SW  main.cpp:939-1013   LCS  main.cpp:1577-1587
 #pragma once
@@ -34,8 +41,8 @@ struct FillArgs {
   int m, n;   // rows, columns
   int S, C;   // strips, steps per tile (multiple of 64)
   int W;      // trace dwords per (lane,k) per strip
-  int go, ge; // gap penalties; with FRAC: floor() of the reference's doubles
-  int fo, fe; // FRAC: 1 if the open / extend penalty has a fractional part
+  int go, ge; // gap penalties in register scale (NW/SW: 4 x floor(penalty); LCS unused)
+  int fo, fe; // FRAC: register-scale unit (4) if the open / extend penalty has a fractional part, else 0
   int alpha;  // profile symbols
   int NP;     // length of one bottom-row ring buffer
   const uint8_t* yenc;   // NW/SW: table index per column; LCS: raw byte.  Padded with zeros.
@@ -60,17 +67,21 @@ __device__ __forceinline__ int dpp_shr1(int old, int src) {  // lane l <- src of
 __device__ __forceinline__ int dpp_shl1(int old, int src) {  // lane l <- src of lane l+1, lane 63 <- old
   return __builtin_amdgcn_update_dpp(old, src, 0x130, 0xf, 0xf, false);
 }
+// rotate-left whose lane 63 is a don't-care: no tie to an old value, so no register copy
+__device__ __forceinline__ int dpp_shl1_any(int src) { return __builtin_amdgcn_mov_dpp(src, 0x130, 0xf, 0xf, false); }
 
 enum { FLAG_FRAC = 1, FLAG_DUMP = 2 };
 
 // score + gap.  The reference adds a double penalty to an int and truncates the sum toward
 // zero (main.cpp:603-604, 625-634, 958-964).  With g = G + f, G = floor(g), 0 < f < 1:
 // trunc(v + g) = w for w >= 0 and w + 1 for w < 0, where w = v + G.
+// `unit` is the value of 1 in the caller's scale (1, or 4 for tagged values; a tag < 4 in the low
+// bits does not change the sign test).
 template <bool FRAC>
-__device__ __forceinline__ int add_gap(int v, int G, int has_frac) {
+__device__ __forceinline__ int add_gap(int v, int G, int frac_unit) {
   const int w = v + G;
   if (!FRAC) return w;
-  return w + (((unsigned)w >> 31) & (unsigned)has_frac);
+  return w + ((w >> 31) & frac_unit);
 }
 
 template <int KIND, int K>
@@ -84,6 +95,7 @@ struct Geo {
 template <int KIND, int K>
 struct Lane {
   int H[K];      // H of the cell to the left, per owned row
+  int Hg[K];     // H + gap_open of the cell to the left (feeds E of this column and F of the row below)
   int E[K];      // E of the cell to the left (unused for LCS)
   int passH;     // H of the lane's bottom row, handed to the lane below at the next step
   int passF;
@@ -102,13 +114,20 @@ __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF,
   constexpr bool DUMP = (FLAGS & FLAG_DUMP) != 0;
   const int go = a.go, ge = a.ge, n = a.n;
   using G = Geo<KIND, K>;
+  // rotate the in-buffers first (lane 63 is a don't-care, so no copy), then let the shifted-in
+  // values overwrite the old in-buffer registers in place
+  const int nibH = dpp_shl1_any(ibH);
+  const int nyb = dpp_shl1_any(yb);
   int up = dpp_shr1(ibH, st.passH);
   int uf = 0;
-  if (KIND != KIND_LCS) uf = dpp_shr1(ibF, st.passF);
+  if (KIND != KIND_LCS) {
+    const int nibF = dpp_shl1_any(ibF);
+    uf = dpp_shr1(ibF, st.passF);
+    ibF = nibF;
+  }
   const int yv = dpp_shr1(yb, st.ypass);
-  ibH = dpp_shl1(ibH, ibH);
-  if (KIND != KIND_LCS) ibF = dpp_shl1(ibF, ibF);
-  yb = dpp_shl1(yb, yb);
+  ibH = nibH;
+  yb = nyb;
 
   uint32_t pw[G::PW];
   if (KIND != KIND_LCS) {
@@ -125,49 +144,56 @@ __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF,
   st.ypass = yv;
   const bool act = BND ? (c >= 0 && c < n) : true;
   int f_last = 0;
+  int upg = (KIND != KIND_LCS) ? add_gap<FRAC>(up, go, a.fo) : 0;  // (H + gap_open) of the cell above, tag 0
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int left = st.H[k];
-    int h, code;
+    int h;
     if (KIND == KIND_LCS) {
       const bool eq = (xr[k] == (uint32_t)yv);
       h = eq ? diag + 1 : max(up, left);
-      code = eq ? 0 : (up >= left ? 2 : 1);
+      const int code = eq ? 0 : (up >= left ? 2 : 1);
+      tacc[k] |= (uint32_t)code << (2 * u);
+      if (BND) h = act ? h : left;
     } else {
-      const int sg = (int)(int8_t)(pw[k / 4] >> (8 * (k & 3)));
-      int f = max(add_gap<FRAC>(up, go, a.fo), add_gap<FRAC>(uf, ge, a.fe));
-      int e = max(add_gap<FRAC>(left, go, a.fo), add_gap<FRAC>(st.E[k], ge, a.fe));
-      int mv = diag + sg;
+      // tagged candidates: see the header of this file
+      const int sg = (int)(int8_t)(pw[k / 4] >> (8 * (k & 3)));  // 4*sigma + 2
+      int f = max(upg, add_gap<FRAC>(uf, ge, a.fe));               // tag 0
+      int e = max(st.Hg[k], add_gap<FRAC>(st.E[k], ge, a.fe));     // tag 1
+      int mv = diag + sg;                                          // tag 2
       if (KIND == KIND_SW) {
         f = max(f, 0);
-        e = max(e, 0);
-        mv = max(mv, 0);
+        e = max(e, 1);
+        mv = max(mv, 2);
       }
-      const int t = max(e, f);
-      h = max(mv, t);
-      code = (mv >= t) ? 0 : (e >= f ? 1 : 2);
-      if (KIND == KIND_SW) code = (h == 0) ? 3 : code;
+      int ht = max(max(mv, e), f);
+      if (KIND == KIND_SW) ht = max(ht, 3);
+      tacc[k] = __builtin_amdgcn_alignbit((uint32_t)ht, tacc[k], 2);
+      h = ht & ~3;
       if (BND) {
         e = act ? e : st.E[k];
         f = act ? f : st.passF;
+        h = act ? h : left;
       }
       st.E[k] = e;
       uf = f;
       f_last = f;
     }
-    if (BND) h = act ? h : left;
     if (KIND == KIND_SW) {
       const bool better = BND ? (act && h > st.best[k]) : (h > st.best[k]);
       st.best[k] = better ? h : st.best[k];
       st.bestc[k] = better ? c : st.bestc[k];
     }
-    tacc[k] |= (uint32_t)code << (2 * u);
     if (DUMP) {
-      if (act && dprow[k] >= 0) a.dp[(size_t)dprow[k] + c + 1] = h;
+      if (act && dprow[k] >= 0) a.dp[(size_t)dprow[k] + c + 1] = (KIND == KIND_LCS) ? h : (h >> 2);
     }
     diag = left;
     st.H[k] = h;
     up = h;
+    if (KIND != KIND_LCS) {
+      upg = add_gap<FRAC>(h, go, a.fo);
+      st.Hg[k] = upg + 1;  // tag 1: this value opens E of the next column
+    }
   }
   st.passH = st.H[K - 1];
   if (KIND != KIND_LCS) st.passF = BND ? (act ? f_last : st.passF) : f_last;
@@ -221,6 +247,7 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
 template <int KIND, int K, int FLAGS>
 __global__ void __launch_bounds__(64) fill_tile(const FillArgs a) {
   constexpr bool DUMP = (FLAGS & FLAG_DUMP) != 0;
+  constexpr int SH = (KIND == KIND_LCS) ? 0 : 2;  // NW / SW registers hold 4*score (+ tag)
   using G = Geo<KIND, K>;
   extern __shared__ uint32_t lds[];
   const int lane = threadIdx.x;
@@ -256,15 +283,15 @@ __global__ void __launch_bounds__(64) fill_tile(const FillArgs a) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const int2 b = a.lb[min(r0 + k + 1, a.m)];
-      st.H[k] = b.x;
-      st.E[k] = b.y;
+      st.H[k] = b.x * (1 << SH);
+      st.E[k] = (KIND == KIND_LCS) ? b.y : b.y * (1 << SH) + 1;
       st.best[k] = 0;
       st.bestc[k] = -1;
     }
     st.passH = st.H[K - 1];
     st.passF = (KIND == KIND_NW) ? kNeg : 0;
     st.ypass = 0;
-    st.dprev = a.lb[min(r0, a.m)].x;
+    st.dprev = a.lb[min(r0, a.m)].x * (1 << SH);
   } else {
     int f = 0;
 #pragma unroll
@@ -285,6 +312,11 @@ __global__ void __launch_bounds__(64) fill_tile(const FillArgs a) {
     }
   }
 
+  if (KIND != KIND_LCS) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) st.Hg[k] = add_gap<(FLAGS & FLAG_FRAC) != 0>(st.H[k], a.go, a.fo) + 1;
+  }
+
 #pragma unroll 1
   for (int b = 0; b < a.C / 64; ++b) {
     const int Tb = T0 + 64 * b;
@@ -301,13 +333,13 @@ __global__ void __launch_bounds__(64) fill_tile(const FillArgs a) {
     if (a.rb) {  // column stripes: the lane's rows froze at the stripe's last column
 #pragma unroll
       for (int k = 0; k < K; ++k)
-        if (r0 + k < a.m) a.rb[r0 + k + 1] = make_int2(st.H[k], st.E[k]);
+        if (r0 + k < a.m) a.rb[r0 + k + 1] = make_int2(st.H[k] >> SH, st.E[k] >> SH);
     }
     if (KIND == KIND_SW) {
 #pragma unroll
       for (int k = 0; k < K; ++k)
         if (r0 + k < a.m) {
-          a.rowbest[r0 + k] = st.best[k];
+          a.rowbest[r0 + k] = st.best[k] >> SH;
           a.rowbestc[r0 + k] = st.bestc[k];
         }
     } else if (s == a.S - 1) {
@@ -315,7 +347,7 @@ __global__ void __launch_bounds__(64) fill_tile(const FillArgs a) {
       if (rl / K == rowg) {
 #pragma unroll
         for (int k = 0; k < K; ++k)
-          if (k == rl % K) *a.score_out = st.H[k];
+          if (k == rl % K) *a.score_out = st.H[k] >> SH;
       }
     }
   } else {
@@ -358,6 +390,7 @@ __global__ void build_profile(const uint8_t* __restrict__ xidx, int m, const int
     for (int k = 0; k < K; ++k) {
       int v = 0;
       if (r0 + k < m) v = sub[(int)xidx[r0 + k] * alpha + sym];
+      v = 4 * v + 2;  // tagged M candidate (host guarantees |sigma| <= 31)
       w[k / 4] |= (uint32_t)(uint8_t)(int8_t)v << (8 * (k & 3));
     }
 #pragma unroll
@@ -397,17 +430,20 @@ struct TraceArgs {
 // (i,j) selects one of the three ballots and count-trailing-ones gives the length of the run of
 // identical moves, which the lanes then emit as bytes in parallel.  One memory round trip per
 // run instead of one per move (the three gathers are in flight together).
-__device__ __forceinline__ uint32_t trace_code(const uint32_t* __restrict__ trace, int i, int j, int lgK, int W) {
+__device__ __forceinline__ uint32_t trace_code(const uint32_t* __restrict__ trace, int i, int j, int lgK, int W, bool tagged) {
   const int r = i - 1, c = j - 1;
   const int g = r >> lgK, k = r & ((1 << lgK) - 1);
   const int s = g >> 6, l = g & 63;
   const int t = c + l;
   const size_t idx = ((((size_t)s * W + (t >> 4)) * 64 + l) << lgK) + k;
-  return (trace[idx] >> (2 * (t & 15))) & 3u;
+  const uint32_t raw = (trace[idx] >> (2 * (t & 15))) & 3u;
+  // NW / SW cells store the winner's tag (M 2, E 1, F 0, SW zero cell 3); LCS stores the op itself
+  return tagged ? (raw == 3u ? 3u : 2u - raw) : raw;
 }
 
 __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
   const int d = threadIdx.x;
+  const bool tagged = a.kind != KIND_LCS;
   int lgK = 0;
   while ((1 << lgK) < a.K) ++lgK;
   int i = a.m, j = a.n;
@@ -433,11 +469,11 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
     const bool vM = (i - d >= 1) && (j - d >= 1);
     const bool vE = (j - d >= 1);
     const bool vF = (i - d >= 1);
-    const uint32_t cM = vM ? trace_code(a.trace, i - d, j - d, lgK, a.W) : 3u;
-    const uint32_t cE = vE ? trace_code(a.trace, i, j - d, lgK, a.W) : 3u;
-    const uint32_t cF = vF ? trace_code(a.trace, i - d, j, lgK, a.W) : 3u;
+    const uint32_t cM = vM ? trace_code(a.trace, i - d, j - d, lgK, a.W, tagged) : 3u;
+    const uint32_t cE = vE ? trace_code(a.trace, i, j - d, lgK, a.W, tagged) : 3u;
+    const uint32_t cF = vF ? trace_code(a.trace, i - d, j, lgK, a.W, tagged) : 3u;
     // touch the next 64 cells of this diagonal so the following iteration finds them in L2
-    if (i - d - 64 >= 1 && j - d - 64 >= 1) warm += trace_code(a.trace, i - d - 64, j - d - 64, lgK, a.W);
+    if (i - d - 64 >= 1 && j - d - 64 >= 1) warm += trace_code(a.trace, i - d - 64, j - d - 64, lgK, a.W, tagged);
     const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cM);
     if (c0 == 3u) break;  // SW stop cell ('X', main.cpp:1233)
     unsigned long long run;

@@ -218,8 +218,11 @@ int check_scoring(sa_ctx* ctx, int kind, const sa_scoring* sc, int64_t m, int64_
   if (kind == KIND_LCS) return SA_OK;
   if (!sc || !sc->sub || !sc->idx256 || sc->alpha < 1 || sc->alpha > 32) return fail(ctx, SA_ERR_ARG, "bad scoring");
   if (!(std::fabs(sc->gap_open) <= 1e6) || !(std::fabs(sc->gap_extend) <= 1e6)) return fail(ctx, SA_ERR_ARG, "gap penalty out of range");
-  const double worst = ((double)m + n_total + 2) * std::max({std::fabs(sc->gap_open) + 1, std::fabs(sc->gap_extend) + 1, 128.0});
-  if (worst > 1.0e9) return fail(ctx, SA_ERR_ARG, "score range would overflow int32");
+  int smax = 0;
+  for (int i = 0; i < sc->alpha * sc->alpha; ++i) smax = std::max(smax, std::abs((int)sc->sub[i]));
+  if (smax > 31) return fail(ctx, SA_ERR_UNSUPPORTED, "substitution scores beyond +-31 do not fit the int8 tagged profile");
+  const double worst = ((double)m + n_total + 2) * std::max({std::fabs(sc->gap_open) + 1, std::fabs(sc->gap_extend) + 1, (double)smax});
+  if (worst > 1.2e8) return fail(ctx, SA_ERR_ARG, "score range would overflow the 4x-scaled int32 arithmetic");
   return SA_OK;
 }
 
@@ -233,10 +236,11 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   const bool dump = (flags & SA_FLAG_KEEP_DP) != 0;
   int go = 0, ge = 0, fo = 0, fe = 0, alpha = 1;
   if (kind != KIND_LCS) {
-    go = (int)std::floor(sc->gap_open);
-    ge = (int)std::floor(sc->gap_extend);
-    fo = sc->gap_open != std::floor(sc->gap_open);
-    fe = sc->gap_extend != std::floor(sc->gap_extend);
+    // register scale of the NW / SW kernels: 4 x score (+ a 2-bit candidate tag, sa_kernels.h)
+    go = 4 * (int)std::floor(sc->gap_open);
+    ge = 4 * (int)std::floor(sc->gap_extend);
+    fo = sc->gap_open != std::floor(sc->gap_open) ? 4 : 0;
+    fe = sc->gap_extend != std::floor(sc->gap_extend) ? 4 : 0;
     alpha = sc->alpha;
   }
   const int fl = ((fo || fe) ? FLAG_FRAC : 0) | (dump ? FLAG_DUMP : 0);
@@ -283,7 +287,9 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
     for (int i = 0; i < m; ++i) xe[i] = sc->idx256[x[i]];
     for (int j = 0; j < n; ++j) ye[j] = sc->idx256[y[j]];
   }
-  const int e_border = (kind == KIND_NW) ? kNeg : 0;  // E[i][0]: main.cpp:619 / :1105
+  // E[i][0]: main.cpp:619 (-inf) / :1105 (0).  The kernel multiplies border values by 4, so -inf
+  // is handed over as INT_MIN/8.
+  const int e_border = (kind == KIND_NW) ? kNeg / 4 : 0;
   std::vector<int> lbh;
   if (first) {
     lbh.resize(((size_t)m + 1) * 2);
@@ -311,7 +317,12 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   // strip 0 reads ring buffer 1: row 0 of the matrix, H[0][j] at p = j + 63
   HIPCK(ctx, hipMemsetAsync(botH, 0, (size_t)2 * NP * 4, st));
   HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)botF, kind == KIND_NW ? kNeg : 0, (size_t)2 * NP, st));
-  if (kind == KIND_NW) HIPCK(ctx, hipMemcpyAsync(botH + NP + 64, rowb.data() + 1, (size_t)n * 4, hipMemcpyHostToDevice, st));
+  std::vector<int> rowb4;
+  if (kind == KIND_NW) {
+    rowb4.resize((size_t)n);
+    for (int j = 0; j < n; ++j) rowb4[j] = 4 * rowb[j + 1];
+    HIPCK(ctx, hipMemcpyAsync(botH + NP + 64, rowb4.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  }
   HIPCK(ctx, hipMemsetAsync(ctx->small.p, 0, 256, st));
   int* d_score = (int*)ctx->small.p;                                           // [0]   NW/LCS score / SW best
   unsigned long long* d_pos = (unsigned long long*)((char*)ctx->small.p + 8);  // [8]   SW end cell
