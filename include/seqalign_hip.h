@@ -94,6 +94,9 @@ void sa_free_result(sa_result* r);
 int sa_release_workspace(sa_ctx* ctx);
 /* tuning overrides, 0 = automatic: rows per lane K in {1,2,4,8}, tile steps C multiple of 64 */
 int sa_set_tuning(sa_ctx* ctx, int rows_per_lane, int tile_steps);
+/* engine options: "persistent" 0/1 (fill as one persistent strip-pipelined launch instead of one
+ * launch per tile diagonal; same results), "waves_per_simd" 1..4 (grid of the persistent launch) */
+int sa_set_option(sa_ctx* ctx, const char* name, int64_t value);
 
 /* The reference's two built-in scoring schemes with default penalties -5/-1
  * (main.cpp:41-43): EDNAFULL indexed by char2idx (including its index-order quirk) and

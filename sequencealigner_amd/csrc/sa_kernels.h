@@ -58,8 +58,22 @@ struct FillArgs {
   int* rowbest;          // SW: best score per row
   int* rowbestc;         // SW: first column (0-based) attaining it
   int* score_out;        // NW/LCS: H[m][n]
-  int d, s_lo;           // launch index, first strip of this launch
+  int d, s_lo, s_hi;     // launch index, first / last strip of this launch
+  // persistent strip pipeline (fill_persistent): one launch, hand-off every 64 steps
+  int* prog;             // [S] blocks of 64 steps completed per strip (zeroed before the launch)
+  int* ticket;           // next strip to hand out (zeroed)
+  int* err;              // set to 1 when a bounded spin ran out (zeroed)
+  int spin_limit;        // polls before a waiting wave gives up
 };
+
+// Inter-wave hand-off of the strip bottom rows inside ONE launch (persistent kernel only).
+// Every store of the handed-off words is an agent-scope relaxed atomic store (global_store ..
+// sc1: write-through), every load of them an agent-scope relaxed atomic load (sc1: not served
+// from this CU's L1), the producer drains vmcnt before one lane raises the strip's progress
+// word the same way, and the consumer reads data only after its poll matched
+// (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads", row 1).
+__device__ __forceinline__ int ld_coherent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coherent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ int dpp_shr1(int old, int src) {  // lane l <- src of lane l-1, lane 0 <- old
   return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false);
@@ -70,7 +84,20 @@ __device__ __forceinline__ int dpp_shl1(int old, int src) {  // lane l <- src of
 // rotate-left whose lane 63 is a don't-care: no tie to an old value, so no register copy
 __device__ __forceinline__ int dpp_shl1_any(int src) { return __builtin_amdgcn_mov_dpp(src, 0x130, 0xf, 0xf, false); }
 
-enum { FLAG_FRAC = 1, FLAG_DUMP = 2 };
+enum { FLAG_FRAC = 1, FLAG_DUMP = 2, FLAG_PERSIST = 4 };
+
+// Workgroups are 4 independent waves (256 threads): the hardware places the 4 waves of one
+// workgroup on the 4 SIMDs of a CU, which single-wave workgroups do not guarantee -- and a wave
+// that shares its SIMD runs at half speed and, in a chained pipeline, sets everybody's pace.
+// Each wave owns a private slice of the dynamic LDS; there is no workgroup barrier anywhere.
+constexpr int kWavesPerBlock = 4;
+
+// LDS written by some lanes of a wave and read by others of the SAME wave: the LDS executes one
+// wave's instructions in order, so only the compiler has to be kept from reordering.
+__device__ __forceinline__ void wave_lds_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
 
 // score + gap.  The reference adds a double penalty to an int and truncates the sum toward
 // zero (main.cpp:603-604, 625-634, 958-964).  With g = G + f, G = floor(g), 0 < f < 1:
@@ -222,8 +249,15 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
   const int* rdF = a.botF + (size_t)((s & 1) ^ 1) * a.NP;
   int* wrH = a.botH + (size_t)(s & 1) * a.NP;
   int* wrF = a.botF + (size_t)(s & 1) * a.NP;
-  int ibH = rdH[Tb + 64 + lane];
-  int ibF = (KIND != KIND_LCS) ? rdF[Tb + 64 + lane] : 0;
+  constexpr bool PERSIST = (FLAGS & FLAG_PERSIST) != 0;
+  int ibH, ibF = 0;
+  if (PERSIST) {
+    ibH = ld_coherent(rdH + Tb + 64 + lane);
+    if (KIND != KIND_LCS) ibF = ld_coherent(rdF + Tb + 64 + lane);
+  } else {
+    ibH = rdH[Tb + 64 + lane];
+    if (KIND != KIND_LCS) ibF = rdF[Tb + 64 + lane];
+  }
   int yb = a.yenc[Tb + lane];
   if (KIND != KIND_LCS) yb *= G::ROWB;
   int obH = 0, obF = 0;
@@ -240,18 +274,70 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
     store_trace<K>(tdst, tacc);
     tdst += 64 * K;
   }
-  wrH[Tb + 1 + lane] = obH;
-  if (KIND != KIND_LCS) wrF[Tb + 1 + lane] = obF;
+  if (PERSIST) {
+    st_coherent(wrH + Tb + 1 + lane, obH);
+    if (KIND != KIND_LCS) st_coherent(wrF + Tb + 1 + lane, obF);
+  } else {
+    wrH[Tb + 1 + lane] = obH;
+    if (KIND != KIND_LCS) wrF[Tb + 1 + lane] = obF;
+  }
+}
+
+// lane state at the first column of a strip, from the left border (values of matrix column 0 of
+// this stripe); NW / SW registers hold 4*score (+ tag)
+template <int KIND, int K, int FLAGS>
+__device__ __forceinline__ void strip_begin(Lane<KIND, K>& st, const FillArgs& a, const int r0) {
+  constexpr int SH = (KIND == KIND_LCS) ? 0 : 2;
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int2 b = a.lb[min(r0 + k + 1, a.m)];
+    st.H[k] = b.x * (1 << SH);
+    st.E[k] = (KIND == KIND_LCS) ? b.y : b.y * (1 << SH) + 1;
+    st.best[k] = 0;
+    st.bestc[k] = -1;
+  }
+  st.passH = st.H[K - 1];
+  st.passF = (KIND == KIND_NW) ? kNeg : 0;
+  st.ypass = 0;
+  st.dprev = a.lb[min(r0, a.m)].x * (1 << SH);
+}
+
+// outputs of a finished strip: right border (column stripes), SW row bests, the final score
+template <int KIND, int K>
+__device__ __forceinline__ void strip_end(const Lane<KIND, K>& st, const FillArgs& a, const int s, const int rowg, const int r0) {
+  constexpr int SH = (KIND == KIND_LCS) ? 0 : 2;
+  if (a.rb) {  // the lane's rows froze at the stripe's last column
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (r0 + k < a.m) a.rb[r0 + k + 1] = make_int2(st.H[k] >> SH, st.E[k] >> SH);
+  }
+  if (KIND == KIND_SW) {
+#pragma unroll
+    for (int k = 0; k < K; ++k)
+      if (r0 + k < a.m) {
+        a.rowbest[r0 + k] = st.best[k] >> SH;
+        a.rowbestc[r0 + k] = st.bestc[k];
+      }
+  } else if (s == a.S - 1) {
+    const int rl = a.m - 1;
+    if (rl / K == rowg) {
+#pragma unroll
+      for (int k = 0; k < K; ++k)
+        if (k == rl % K) *a.score_out = st.H[k] >> SH;
+    }
+  }
 }
 
 template <int KIND, int K, int FLAGS>
-__global__ void __launch_bounds__(64) fill_tile(const FillArgs a) {
+__global__ void __launch_bounds__(64 * kWavesPerBlock) fill_tile(const FillArgs a) {
   constexpr bool DUMP = (FLAGS & FLAG_DUMP) != 0;
-  constexpr int SH = (KIND == KIND_LCS) ? 0 : 2;  // NW / SW registers hold 4*score (+ tag)
   using G = Geo<KIND, K>;
-  extern __shared__ uint32_t lds[];
-  const int lane = threadIdx.x;
-  const int s = a.s_lo + blockIdx.x;
+  extern __shared__ uint32_t lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  uint32_t* lds = lds_all + wave * (a.alpha * 64 * G::PW);
+  const int s = a.s_lo + blockIdx.x * kWavesPerBlock + wave;
+  if (s > a.s_hi) return;
   const int q = a.d - s;
   const int qmin = (64 * s) / a.C;
   const int qmax = (64 * s + a.n + 62) / a.C;
@@ -269,7 +355,7 @@ __global__ void __launch_bounds__(64) fill_tile(const FillArgs a) {
     for (int k = 0; k < K; ++k) xr[k] = 0;
     const uint32_t* gp = a.prof + (size_t)s * a.alpha * 64 * G::PW;
     for (int i = lane; i < a.alpha * 64 * G::PW; i += 64) lds[i] = gp[i];
-    __syncthreads();
+    wave_lds_fence();
   }
   const char* ldsLane = reinterpret_cast<const char*>(lds) + lane * 4 * G::PW;
 
@@ -280,18 +366,7 @@ __global__ void __launch_bounds__(64) fill_tile(const FillArgs a) {
   Lane<KIND, K> st;
   int* sp = a.state + ((size_t)s * G::NF) * 64 + lane;
   if (q == qmin) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      const int2 b = a.lb[min(r0 + k + 1, a.m)];
-      st.H[k] = b.x * (1 << SH);
-      st.E[k] = (KIND == KIND_LCS) ? b.y : b.y * (1 << SH) + 1;
-      st.best[k] = 0;
-      st.bestc[k] = -1;
-    }
-    st.passH = st.H[K - 1];
-    st.passF = (KIND == KIND_NW) ? kNeg : 0;
-    st.ypass = 0;
-    st.dprev = a.lb[min(r0, a.m)].x * (1 << SH);
+    strip_begin<KIND, K, FLAGS>(st, a, r0);
   } else {
     int f = 0;
 #pragma unroll
@@ -330,26 +405,7 @@ __global__ void __launch_bounds__(64) fill_tile(const FillArgs a) {
   }
 
   if (q == qmax) {
-    if (a.rb) {  // column stripes: the lane's rows froze at the stripe's last column
-#pragma unroll
-      for (int k = 0; k < K; ++k)
-        if (r0 + k < a.m) a.rb[r0 + k + 1] = make_int2(st.H[k] >> SH, st.E[k] >> SH);
-    }
-    if (KIND == KIND_SW) {
-#pragma unroll
-      for (int k = 0; k < K; ++k)
-        if (r0 + k < a.m) {
-          a.rowbest[r0 + k] = st.best[k] >> SH;
-          a.rowbestc[r0 + k] = st.bestc[k];
-        }
-    } else if (s == a.S - 1) {
-      const int rl = a.m - 1;
-      if (rl / K == rowg) {
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-          if (k == rl % K) *a.score_out = st.H[k] >> SH;
-      }
-    }
+    strip_end<KIND, K>(st, a, s, rowg, r0);
   } else {
     int f = 0;
 #pragma unroll
@@ -368,6 +424,86 @@ __global__ void __launch_bounds__(64) fill_tile(const FillArgs a) {
 #pragma unroll
       for (int k = 0; k < K; ++k) sp[64 * f++] = st.bestc[k];
     }
+  }
+}
+
+// ---- persistent strip pipeline ---------------------------------------------------------------
+// One launch for the whole fill.  A wave draws strips from a ticket counter in ascending order and
+// sweeps each one block by block (64 steps); before block b of strip s it waits until strip s-1
+// has published b+2 finished blocks (it reads bottom-row entries that strip s-1 writes at the end
+// of its block b+1), so consecutive strips run 128 steps apart and nothing is saved or restored
+// between tiles.  Deadlock-free for any grid size: tickets are only handed to running waves, in
+// order, so the lowest unfinished strip is always held by a resident wave whose predecessor is
+// complete.  Every spin is bounded (spin_limit); a wave that gives up raises *err and every
+// waiting wave leaves when it sees it.
+template <int KIND, int K, int FLAGS>
+__global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const FillArgs a) {
+  using G = Geo<KIND, K>;
+  constexpr int PF = FLAGS | FLAG_PERSIST;
+  extern __shared__ uint32_t lds_all[];
+  const int lane = threadIdx.x & 63;
+  uint32_t* lds = lds_all + (threadIdx.x >> 6) * (a.alpha * 64 * G::PW);
+  const int NB = (a.n + 63 + 63) / 64;  // blocks with at least one active lane
+  const char* ldsLane = reinterpret_cast<const char*>(lds) + lane * 4 * G::PW;
+  int dprow[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) dprow[k] = -1;
+
+  while (true) {
+    int s = 0;
+    if (lane == 0) s = atomicAdd(a.ticket, 1);
+    s = __builtin_amdgcn_readfirstlane(s);
+    if (s >= a.S) break;
+    const int rowg = s * 64 + lane;
+    const int r0 = rowg * K;
+    uint32_t xr[K];
+    if (KIND == KIND_LCS) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) xr[k] = a.xpad[(size_t)r0 + k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) xr[k] = 0;
+      wave_lds_fence();  // the previous strip's LDS reads are done
+      const uint32_t* gp = a.prof + (size_t)s * a.alpha * 64 * G::PW;
+      for (int i = lane; i < a.alpha * 64 * G::PW; i += 64) lds[i] = gp[i];
+      wave_lds_fence();
+    }
+    Lane<KIND, K> st;
+    strip_begin<KIND, K, FLAGS>(st, a, r0);
+    if (KIND != KIND_LCS) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) st.Hg[k] = add_gap<(FLAGS & FLAG_FRAC) != 0>(st.H[k], a.go, a.fo) + 1;
+    }
+    bool dead = false;
+#pragma unroll 1
+    for (int b = 0; b < NB; ++b) {
+      const int Tb = 64 * b;
+      if (s > 0) {
+        const int need = min(b + 2, NB);
+        int spins = 0;
+        while (ld_coherent(a.prog + (s - 1)) < need) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > a.spin_limit || ((spins & 255) == 0 && ld_coherent(a.err) != 0)) {
+            dead = true;
+            break;
+          }
+        }
+        if (dead) break;
+        asm volatile("" ::: "memory");  // data loads stay behind the poll
+      }
+      const bool interior = (Tb >= 64) && (Tb + 63 < a.n);
+      if (interior)
+        run_block<KIND, K, false, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow);
+      else
+        run_block<KIND, K, true, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have completed
+      if (lane == 0) st_coherent(a.prog + s, b + 1);
+    }
+    if (dead) {
+      if (lane == 0) st_coherent(a.err, 1);
+      break;
+    }
+    strip_end<KIND, K>(st, a, s, rowg, r0);
   }
 }
 

@@ -38,11 +38,14 @@ struct sa_ctx {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   std::string err;
   int force_K = 0, force_C = 0;
+  int persist = 1;  // 1: persistent strip pipeline (one launch) where it applies
+  int wps = 1;      // persistent kernel: waves per SIMD to launch
+  int n_cu = 256;
   // cached device workspaces
   Buf xenc, yenc, prof, sub, colb, bot, state, trace, rowbest, small, ops;
   // batch workspaces
   Buf b_seq, b_desc, b_out;
-  Buf lbuf, dpbuf;
+  Buf lbuf, dpbuf, pbuf;
   // geometry of the last fill, for the traceback that follows it
   struct {
     int valid = 0, kind = 0, m = 0, n = 0, K = 0, W = 0, first_stripe = 1;
@@ -134,17 +137,27 @@ void launch_fill(int K, int fl, dim3 grid, size_t lds, hipStream_t st, const Fil
   // instantiated combinations: plain K in {1,2,4,8}; FRAC only with K=2; DUMP (+FRAC) only with K=1
   if (fl == 0) {
     switch (K) {
-      case 1: hipLaunchKernelGGL((fill_tile<KIND, 1, 0>), grid, dim3(64), lds, st, a); break;
-      case 2: hipLaunchKernelGGL((fill_tile<KIND, 2, 0>), grid, dim3(64), lds, st, a); break;
-      case 4: hipLaunchKernelGGL((fill_tile<KIND, 4, 0>), grid, dim3(64), lds, st, a); break;
-      default: hipLaunchKernelGGL((fill_tile<KIND, 8, 0>), grid, dim3(64), lds, st, a); break;
+      case 1: hipLaunchKernelGGL((fill_tile<KIND, 1, 0>), grid, dim3(64 * kWavesPerBlock), lds, st, a); break;
+      case 2: hipLaunchKernelGGL((fill_tile<KIND, 2, 0>), grid, dim3(64 * kWavesPerBlock), lds, st, a); break;
+      case 4: hipLaunchKernelGGL((fill_tile<KIND, 4, 0>), grid, dim3(64 * kWavesPerBlock), lds, st, a); break;
+      default: hipLaunchKernelGGL((fill_tile<KIND, 8, 0>), grid, dim3(64 * kWavesPerBlock), lds, st, a); break;
     }
   } else if (fl == FLAG_FRAC) {
-    hipLaunchKernelGGL((fill_tile<KIND, 2, FLAG_FRAC>), grid, dim3(64), lds, st, a);
+    hipLaunchKernelGGL((fill_tile<KIND, 2, FLAG_FRAC>), grid, dim3(64 * kWavesPerBlock), lds, st, a);
   } else if (fl == FLAG_DUMP) {
-    hipLaunchKernelGGL((fill_tile<KIND, 1, FLAG_DUMP>), grid, dim3(64), lds, st, a);
+    hipLaunchKernelGGL((fill_tile<KIND, 1, FLAG_DUMP>), grid, dim3(64 * kWavesPerBlock), lds, st, a);
   } else {
-    hipLaunchKernelGGL((fill_tile<KIND, 1, FLAG_DUMP | FLAG_FRAC>), grid, dim3(64), lds, st, a);
+    hipLaunchKernelGGL((fill_tile<KIND, 1, FLAG_DUMP | FLAG_FRAC>), grid, dim3(64 * kWavesPerBlock), lds, st, a);
+  }
+}
+
+template <int KIND>
+void launch_persistent(int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a) {
+  switch (K) {
+    case 1: hipLaunchKernelGGL((fill_persistent<KIND, 1, 0>), grid, dim3(64 * kWavesPerBlock), lds, st, a); break;
+    case 2: hipLaunchKernelGGL((fill_persistent<KIND, 2, 0>), grid, dim3(64 * kWavesPerBlock), lds, st, a); break;
+    case 4: hipLaunchKernelGGL((fill_persistent<KIND, 4, 0>), grid, dim3(64 * kWavesPerBlock), lds, st, a); break;
+    default: hipLaunchKernelGGL((fill_persistent<KIND, 8, 0>), grid, dim3(64 * kWavesPerBlock), lds, st, a); break;
   }
 }
 
@@ -245,10 +258,23 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   }
   const int fl = ((fo || fe) ? FLAG_FRAC : 0) | (dump ? FLAG_DUMP : 0);
   Tuning tun = choose_tuning(ctx, kind, m, n, sd ? sd->col_begin : 0);
-  if (fl & FLAG_DUMP)
+  // persistent strip pipeline: whole matrix on this GPU, plain integral configuration
+  const bool persist = ctx->persist && fl == 0 && (!sd || (sd->is_first && sd->is_last));
+  if (fl & FLAG_DUMP) {
     tun.K = 1, tun.C = 64;
-  else if (fl & FLAG_FRAC)
+  } else if (fl & FLAG_FRAC) {
     tun.K = 2;
+  } else if (persist) {
+    // as many rows per lane as still leave every SIMD a strip of its own
+    tun.K = 1;
+    for (int K : {8, 4, 2})
+      if ((m + 64 * K - 1) / (64 * K) >= ctx->n_cu) {
+        tun.K = K;
+        break;
+      }
+    if (ctx->force_K) tun.K = ctx->force_K;
+    tun.C = 64;
+  }
   const int K = tun.K, C = tun.C;
   const int PW = (K <= 4) ? 1 : K / 4;
   const int S = (m + 64 * K - 1) / (64 * K);
@@ -268,6 +294,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   if ((rc = ensure(ctx, ctx->bot, (size_t)4 * NP * 4))) return rc;
   if ((rc = ensure(ctx, ctx->state, (size_t)S * NF * 64 * 4))) return rc;
   if ((rc = ensure(ctx, ctx->small, 256))) return rc;
+  if (persist && (rc = ensure(ctx, ctx->pbuf, ((size_t)S + 64) * 4))) return rc;
   if ((rc = ensure(ctx, ctx->ops, (size_t)m + n + 64))) return rc;
   if (kind != KIND_LCS) {
     if ((rc = ensure(ctx, ctx->prof, (size_t)S * alpha * 64 * PW * 4))) return rc;
@@ -358,7 +385,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   a.rowbestc = a.rowbest ? a.rowbest + m : nullptr;
   a.score_out = d_score;
 
-  const size_t lds = (kind == KIND_LCS) ? 0 : (size_t)alpha * 64 * PW * 4;
+  const size_t lds = (kind == KIND_LCS) ? 0 : (size_t)alpha * 64 * PW * 4 * kWavesPerBlock;
   auto f_lo = [&](int s) { return (long long)s + (64LL * s) / C; };
   auto f_hi = [&](int s) { return (long long)s + (64LL * s + n + 62) / C; };
   const long long dmax = f_hi(S - 1);
@@ -369,8 +396,25 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   const int64_t n_chunks = sd ? (m + R - 1) / R : 0;
   int64_t chunks_in = 0, chunks_out = 0;
   int slo = 0, shi = -1, launches = 0;
+  if (persist) {
+    HIPCK(ctx, hipMemsetAsync(ctx->pbuf.p, 0, ((size_t)S + 64) * 4, st));
+    a.prog = (int*)ctx->pbuf.p + 64;
+    a.ticket = (int*)ctx->pbuf.p;
+    a.err = (int*)ctx->small.p + 40;  // byte 160 of the small block, read back with the score
+    a.spin_limit = 1 << 22;
+  }
   HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
-  for (long long d = 0; d <= dmax; ++d) {
+  if (persist) {
+    const dim3 grid(std::min((S + kWavesPerBlock - 1) / kWavesPerBlock, ctx->n_cu * std::max(1, ctx->wps)));
+    if (kind == KIND_NW)
+      launch_persistent<KIND_NW>(K, grid, lds, st, a);
+    else if (kind == KIND_SW)
+      launch_persistent<KIND_SW>(K, grid, lds, st, a);
+    else
+      launch_persistent<KIND_LCS>(K, grid, lds, st, a);
+    launches = 1;
+  }
+  for (long long d = 0; !persist && d <= dmax; ++d) {
     while (shi + 1 < S && f_lo(shi + 1) <= d) ++shi;
     while (slo < S && f_hi(slo) < d) ++slo;
     if (slo > shi) continue;
@@ -383,7 +427,8 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
     }
     a.d = (int)d;
     a.s_lo = slo;
-    const dim3 grid(shi - slo + 1);
+    a.s_hi = shi;
+    const dim3 grid((shi - slo + kWavesPerBlock) / kWavesPerBlock);
     if (kind == KIND_NW)
       launch_fill<KIND_NW>(K, fl, grid, lds, st, a);
     else if (kind == KIND_SW)
@@ -430,6 +475,7 @@ int traceback_impl(sa_ctx* ctx, int start_i, int start_j, bool want_tb, sa_resul
     int score;
     int pad;
     unsigned long long pos;
+    int rest[40];
   } h_sc{};
   long long h_hdr[5] = {0, 0, 0, 0, 0};
   if (want_tb) {
@@ -451,8 +497,10 @@ int traceback_impl(sa_ctx* ctx, int start_i, int start_j, bool want_tb, sa_resul
     HIPCK(ctx, hipGetLastError());
     HIPCK(ctx, hipMemcpyAsync(h_hdr, d_hdr, sizeof h_hdr, hipMemcpyDeviceToHost, st));
   }
-  HIPCK(ctx, hipMemcpyAsync(&h_sc, ctx->small.p, 16, hipMemcpyDeviceToHost, st));
+  HIPCK(ctx, hipMemcpyAsync(&h_sc, ctx->small.p, sizeof h_sc, hipMemcpyDeviceToHost, st));
   HIPCK(ctx, hipStreamSynchronize(st));
+  if (h_sc.rest[36] != 0)  // int index 40 of the small block
+    return fail(ctx, SA_ERR_HIP, "persistent fill: a bounded wait on the previous strip expired (results discarded)");
   if (want_tb && h_hdr[0] > 0) {
     out->ops = (uint8_t*)malloc((size_t)h_hdr[0]);
     if (!out->ops) return fail(ctx, SA_ERR_NOMEM, "host malloc of %lld ops failed", h_hdr[0]);
@@ -792,6 +840,8 @@ sa_ctx* sa_create(int device_id) {
   }
   sa_ctx* c = new sa_ctx;
   c->device = device_id;
+  c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (const char* e = getenv("SA_PERSIST")) c->persist = atoi(e);
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return nullptr;
@@ -832,11 +882,24 @@ int sa_set_tuning(sa_ctx* c, int K, int C) {
   return SA_OK;
 }
 
+int sa_set_option(sa_ctx* c, const char* name, int64_t value) {
+  if (!c || !name) return SA_ERR_ARG;
+  if (!strcmp(name, "persistent")) {
+    c->persist = value != 0;
+  } else if (!strcmp(name, "waves_per_simd")) {
+    if (value < 1 || value > 4) return fail(c, SA_ERR_ARG, "waves_per_simd must be 1..4");
+    c->wps = (int)value;
+  } else {
+    return fail(c, SA_ERR_ARG, "unknown option %s", name);
+  }
+  return SA_OK;
+}
+
 int sa_release_workspace(sa_ctx* c) {
   if (!c) return SA_ERR_ARG;
   (void)hipSetDevice(c->device);
   for (Buf* b : {&c->xenc, &c->yenc, &c->prof, &c->sub, &c->colb, &c->bot, &c->state, &c->trace, &c->rowbest, &c->small,
-                 &c->ops, &c->b_seq, &c->b_desc, &c->b_out, &c->lbuf, &c->dpbuf})
+                 &c->ops, &c->b_seq, &c->b_desc, &c->b_out, &c->lbuf, &c->dpbuf, &c->pbuf})
     release(*b);
   return SA_OK;
 }

@@ -132,6 +132,8 @@ def load_library() -> C.CDLL:
     L.sa_set_stream.argtypes = [vp, vp]
     L.sa_set_tuning.argtypes = [vp, C.c_int, C.c_int]
     L.sa_release_workspace.argtypes = [vp]
+    L.sa_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.sa_set_option.restype = C.c_int
     L.sa_free_result.argtypes = [C.POINTER(_Result)]
     L.sa_free_result.restype = None
     L.sa_builtin_scoring.argtypes = [C.c_int]
@@ -208,6 +210,11 @@ class Engine:
 
     def set_tuning(self, rows_per_lane=0, tile_steps=0):
         rc = self.lib.sa_set_tuning(self.ctx, rows_per_lane, tile_steps)
+        if rc:
+            raise SeqAlignError(rc, self.lib.sa_last_error(self.ctx).decode())
+
+    def set_option(self, name, value):
+        rc = self.lib.sa_set_option(self.ctx, name.encode(), int(value))
         if rc:
             raise SeqAlignError(rc, self.lib.sa_last_error(self.ctx).decode())
 

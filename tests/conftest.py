@@ -22,12 +22,32 @@ def oracle():
 
 
 @pytest.fixture(scope="session")
-def engine():
+def _engine_session():
     import sequencealigner_amd as sa
 
     eng = sa.Engine(0)  # raises loudly when the HIP library or the GPU is missing
     yield eng
     eng.close()
+
+
+@pytest.fixture()
+def engine(_engine_session):
+    """The engine in its default configuration (persistent strip pipeline, automatic tuning)."""
+    eng = _engine_session
+    eng.set_option("persistent", 1)
+    eng.set_option("waves_per_simd", 1)
+    eng.set_tuning(0, 0)
+    yield eng
+    eng.set_option("persistent", 1)
+    eng.set_option("waves_per_simd", 1)
+    eng.set_tuning(0, 0)
+
+
+@pytest.fixture(params=["persistent", "launches"])
+def engine_both(engine, request):
+    """Both fill schedules: one persistent launch / one launch per tile diagonal."""
+    engine.set_option("persistent", 1 if request.param == "persistent" else 0)
+    yield engine
 
 
 DNA = "ACGT"

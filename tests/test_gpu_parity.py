@@ -34,7 +34,8 @@ SHAPES = [(1, 1), (1, 7), (7, 1), (2, 3), (63, 64), (64, 63), (65, 65), (100, 25
 
 @pytest.mark.parametrize("kind", ["nw", "sw", "lcs"])
 @pytest.mark.parametrize("K", [1, 2, 4, 8])
-def test_random_dna_all_tilings(engine, oracle, kind, K):
+def test_random_dna_all_tilings(engine_both, oracle, kind, K):
+    engine = engine_both
     rng = np.random.default_rng(100 + K)
     for C in (64, 128, 256):
         engine.set_tuning(K, C)
@@ -46,7 +47,8 @@ def test_random_dna_all_tilings(engine, oracle, kind, K):
 
 
 @pytest.mark.parametrize("kind", ["nw", "sw", "lcs"])
-def test_similar_pairs_auto_tuning(engine, oracle, kind):
+def test_similar_pairs_auto_tuning(engine_both, oracle, kind):
+    engine = engine_both
     rng = np.random.default_rng(7)
     engine.set_tuning(0, 0)
     for m in (500, 3000, 6000):
@@ -56,7 +58,8 @@ def test_similar_pairs_auto_tuning(engine, oracle, kind):
 
 
 @pytest.mark.parametrize("kind", ["nw", "sw"])
-def test_protein_full_alphabet(engine, oracle, kind):
+def test_protein_full_alphabet(engine_both, oracle, kind):
+    engine = engine_both
     rng = np.random.default_rng(11)
     for K in (1, 4, 8):
         engine.set_tuning(K, 128)
@@ -80,7 +83,8 @@ def test_iupac_dna_index_quirk(engine, oracle, kind):
 
 
 @pytest.mark.parametrize("kind", ["nw", "sw", "lcs"])
-def test_tie_storms(engine, oracle, kind):
+def test_tie_storms(engine_both, oracle, kind):
+    engine = engine_both
     """Low-complexity inputs where every comparison ties: tie-breaks must survive the
     anti-diagonal evaluation order."""
     cases = [("A" * 300, "A" * 257), ("AC" * 200, "CA" * 180), ("ACGT" * 100, "ACGT" * 90 + "TTTT"),
@@ -94,7 +98,8 @@ def test_tie_storms(engine, oracle, kind):
 
 @pytest.mark.parametrize("go,ge", [(-10.0, -1.0), (-2.0, -2.0), (-1.0, -3.0), (0.0, 0.0), (-11.0, -1.0), (-3.0, 0.0)])
 @pytest.mark.parametrize("kind", ["nw", "sw"])
-def test_integral_gap_settings(engine, oracle, kind, go, ge):
+def test_integral_gap_settings(engine_both, oracle, kind, go, ge):
+    engine = engine_both
     rng = np.random.default_rng(17)
     x = rand_seq(rng, 700, DNA)
     y = mutate(rng, x, DNA, 0.1, 0.05, 0.05)
@@ -126,7 +131,8 @@ def test_invalid_residue_reports_reference_pair(engine, oracle):
     assert g.score == o.score and np.array_equal(g.ops, o.ops)
 
 
-def test_medium_dna_20k(engine, oracle):
+def test_medium_dna_20k(engine_both, oracle):
+    engine = engine_both
     rng = np.random.default_rng(23)
     x = rand_seq(rng, 20000, DNA)
     y = mutate(rng, x, DNA)
