@@ -13,6 +13,8 @@ orchestration is exercised on CPU by the tests with an oracle-backed engine.
 """
 from __future__ import annotations
 
+import contextlib
+
 import numpy as np
 
 from .engine import SA_EV_NEED_LEFT, AlignResult
@@ -31,7 +33,13 @@ class GpuStripeEngine:
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
         self.eng = Engine(device_index)
-        self.eng.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+        # An explicit stream: torch's default stream has handle 0, which the C-ABI reads as "use
+        # the ctx's own stream" -- and then the kernels would not be ordered with RCCL's send/recv.
+        self.stream = torch.cuda.Stream(device=self.device)
+        self.eng.set_stream(self.stream.cuda_stream)
+
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
 
     def alloc_border(self, m):
         return self.torch.zeros((m + 1, 2), dtype=self.torch.int32, device=self.device)
@@ -74,6 +82,11 @@ class StripedAligner:
         if G == 1 or m == 0 or n < self.min_stripe_cols * G:
             return self._on_rank0(kind, x, y, mode, gap_open, gap_extend)
 
+        with (E.stream_context() if hasattr(E, "stream_context") else contextlib.nullcontext()):
+            return self._align_striped(kind, x, y, m, n, mode, gap_open, gap_extend)
+
+    def _align_striped(self, kind, x, y, m, n, mode, gap_open, gap_extend) -> AlignResult:
+        E, dist, g, G = self.engine, self.dist, self.rank, self.world
         bounds = [n * k // G for k in range(G + 1)]
         c0, c1 = bounds[g], bounds[g + 1]
         ng = c1 - c0
@@ -133,6 +146,12 @@ class StripedAligner:
 
     def _on_rank0(self, kind, x, y, mode, go, ge) -> AlignResult:
         """Inputs too small to stripe: rank 0 aligns, everybody learns the score."""
+        E, dist = self.engine, self.dist
+        ctx = E.stream_context() if hasattr(E, "stream_context") else contextlib.nullcontext()
+        with ctx:
+            return self._on_rank0_inner(kind, x, y, mode, go, ge)
+
+    def _on_rank0_inner(self, kind, x, y, mode, go, ge) -> AlignResult:
         E, dist = self.engine, self.dist
         if self.rank == 0:
             r = E.whole(kind, x, y, mode, go, ge)

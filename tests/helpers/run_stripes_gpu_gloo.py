@@ -1,0 +1,69 @@
+"""Launched by tests/test_gpu_stripes.py::test_striped_aligner_two_processes_one_gpu under
+torch.distributed.run: two (or more) processes share GPU 0, each runs the REAL GpuStripeEngine
+(HIP kernels, torch stream, torch CUDA border tensors); only the transport is swapped: gloo moves
+the border chunks through host memory because RCCL cannot put two ranks on one device.  Checks the
+stitched result against the oracle on rank 0."""
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent.parent
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+torch.cuda.init()  # before the engine loads its HIP runtime (same order as bench.py)
+
+from oracle import Oracle
+from sequencealigner_amd.stripes import GpuStripeEngine, StripedAligner
+from sequencealigner_amd.synth import dna_pair
+
+
+class GlooForCuda:
+    """send/recv/broadcast of CUDA tensors over gloo by staging through the host."""
+
+    def __init__(self):
+        self.pending = []
+
+    def recv(self, t, src):
+        tmp = torch.empty(t.shape, dtype=t.dtype, device="cpu")
+        dist.recv(tmp, src=src)
+        t.copy_(tmp)
+
+    def send(self, t, dst):
+        dist.send(t.cpu(), dst=dst)
+
+    def isend(self, t, dst):
+        return dist.isend(t.cpu(), dst=dst)
+
+    def broadcast(self, t, src):
+        tmp = t.cpu()
+        dist.broadcast(tmp, src=src)
+        t.copy_(tmp)
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    al = StripedAligner(0, rank, world, GlooForCuda(), engine=GpuStripeEngine(0), chunk_rows=512, min_stripe_cols=64)
+    orc = Oracle()
+    ok = True
+    for n, seed, rel in [(3000, 1, True), (20000, 2, True), (5000, 3, False), (100, 4, True)]:
+        x, y = dna_pair(n, seed=seed, related=rel)
+        for kind in ("nw", "lcs"):
+            r = al.align(kind, x, y, "dna")
+            want = orc.lcs(x, y, packed=True) if kind == "lcs" else orc.nw(x, y, "dna", packed=True)
+            good = r.score == want.score and (rank != 0 or np.array_equal(r.ops, want.ops))
+            if not good:
+                print(f"rank {rank}: MISMATCH {kind} n={n}: {r.score} vs {want.score}", flush=True)
+            ok = ok and good
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"rank {rank}: {'GPU_STRIPES_OK' if ok else 'GPU_STRIPES_FAIL'}", flush=True)
+    sys.exit(0 if ok else 1)
+
+
+if __name__ == "__main__":
+    main()

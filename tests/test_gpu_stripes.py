@@ -100,3 +100,21 @@ def test_stripes_protein_and_gaps(engine, oracle):
         want = oracle.nw(x, y, "protein", go, ge)
         score, ops, _ = striped(engine, "nw", x, y, 3, "protein", go, ge, 256)
         assert score == want.score and np.array_equal(ops, want.ops)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_striped_aligner_processes_share_one_gpu(world):
+    """The real stripe engine (HIP kernels, torch stream and border tensors, event callbacks,
+    traceback chain, op gather) in `world` processes on GPU 0; gloo carries the chunks."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    port = 29700 + world + (os.getpid() % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(root / "tests" / "helpers" / "run_stripes_gpu_gloo.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="2"))
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert p.stdout.count("GPU_STRIPES_OK") == world, p.stdout[-3000:]
