@@ -1,0 +1,54 @@
+"""Full-size parity (BASELINE.json config 4: 1 Mb x 1 Mb), where neither the reference (5 TB) nor
+the full oracle can run.  Size-independent checks:
+  * NW: score AND the complete op list equal the banded oracle's (same recurrence and tie-breaks
+    restricted to |j - i*n/m| <= 1024; exact because the traced path never comes near the band
+    edge, which the oracle reports), ~30 s of host time;
+  * the two independent fill schedules (persistent pipeline / per-diagonal launches) agree bit
+    for bit;
+  * LCS: the op list is a valid common subsequence walk whose diagonal moves all match and whose
+    length is the reported score, it consumes exactly m and n residues, and both schedules agree.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pair_1mb():
+    from sequencealigner_amd.synth import dna_pair
+
+    return dna_pair(1_000_000, seed=1234)
+
+
+def test_nw_1mb_equals_banded_oracle_and_both_schedules(engine, oracle, pair_1mb):
+    x, y = pair_1mb
+    want, touched = oracle.nw_banded(x, y, 1024, "dna")
+    assert want.rc == 0 and touched == 0
+    engine.set_option("persistent", 1)
+    a = engine.nw(x, y, "dna")
+    assert a.n_launches == 1
+    assert a.score == want.score == 4322728
+    assert len(a.ops) == len(want.ops) and np.array_equal(a.ops, want.ops)
+    engine.set_option("persistent", 0)
+    b = engine.nw(x, y, "dna")
+    assert b.n_launches > 1000
+    assert b.score == a.score and np.array_equal(a.ops, b.ops)
+
+
+def test_lcs_1mb_properties(engine, pair_1mb):
+    x, y = pair_1mb
+    engine.set_option("persistent", 1)
+    a = engine.lcs(x, y)
+    ops = a.ops
+    takes_x, takes_y = ops != 1, ops != 2
+    assert int(takes_x.sum()) == len(x) and int(takes_y.sum()) == len(y)
+    xi = len(x) - np.cumsum(takes_x)
+    yj = len(y) - np.cumsum(takes_y)
+    diag = ops == 0
+    assert np.array_equal(x[xi[diag]], y[yj[diag]])       # every diagonal move is a match
+    assert int(diag.sum()) == a.score                     # and their number is the LCS length
+    assert a.start == (0, 0) and a.end == (len(x), len(y))
+    engine.set_option("persistent", 0)
+    b = engine.lcs(x, y)
+    assert b.score == a.score and np.array_equal(a.ops, b.ops)
