@@ -240,17 +240,16 @@ __device__ __forceinline__ void store_trace(uint32_t* dst, const uint32_t (&t)[K
   }
 }
 
-// 64 steps of one strip (one bottom-row hand-off in, one out).
-template <int KIND, int K, bool BND, int FLAGS>
-__device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, const int s, const int Tb,
-                                          const int lane, const char* ldsLane, const uint32_t (&xr)[K], int* dprow) {
+// loads of one block's inputs: the 64 bottom-row entries of the strip above (in-buffers) and the
+// 64 target symbols lane 0 will consume
+template <int KIND, int K, int FLAGS>
+__device__ __forceinline__ void load_block_inputs(const FillArgs& a, const int s, const int Tb, const int lane, int& ibH,
+                                                  int& ibF, int& yb) {
   using G = Geo<KIND, K>;
+  constexpr bool PERSIST = (FLAGS & FLAG_PERSIST) != 0;
   const int* rdH = a.botH + (size_t)((s & 1) ^ 1) * a.NP;
   const int* rdF = a.botF + (size_t)((s & 1) ^ 1) * a.NP;
-  int* wrH = a.botH + (size_t)(s & 1) * a.NP;
-  int* wrF = a.botF + (size_t)(s & 1) * a.NP;
-  constexpr bool PERSIST = (FLAGS & FLAG_PERSIST) != 0;
-  int ibH, ibF = 0;
+  ibF = 0;
   if (PERSIST) {
     ibH = ld_coherent(rdH + Tb + 64 + lane);
     if (KIND != KIND_LCS) ibF = ld_coherent(rdF + Tb + 64 + lane);
@@ -258,8 +257,23 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
     ibH = rdH[Tb + 64 + lane];
     if (KIND != KIND_LCS) ibF = rdF[Tb + 64 + lane];
   }
-  int yb = a.yenc[Tb + lane];
+  yb = a.yenc[Tb + lane];
   if (KIND != KIND_LCS) yb *= G::ROWB;
+}
+
+struct NoHook {
+  __device__ __forceinline__ void operator()(int) const {}
+};
+
+// 64 steps of one strip (one bottom-row hand-off in, one out).  `hook(sub)` runs after each of
+// the four 16-step sub-blocks (the persistent kernel hides its polls / prefetches there).
+template <int KIND, int K, bool BND, int FLAGS, typename Hook>
+__device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, const int s, const int Tb,
+                                          const int lane, const char* ldsLane, const uint32_t (&xr)[K], int* dprow,
+                                          int ibH, int ibF, int yb, Hook&& hook) {
+  constexpr bool PERSIST = (FLAGS & FLAG_PERSIST) != 0;
+  int* wrH = a.botH + (size_t)(s & 1) * a.NP;
+  int* wrF = a.botF + (size_t)(s & 1) * a.NP;
   int obH = 0, obF = 0;
   uint32_t* tdst = a.trace + (((size_t)s * a.W + (Tb >> 4)) * 64 + lane) * K;
 #pragma unroll 1
@@ -273,6 +287,7 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
       lane_step<KIND, K, BND, FLAGS>(st, ibH, ibF, yb, obH, obF, tacc, u, ldsLane, xr, a, cbase + u, dprow);
     store_trace<K>(tdst, tacc);
     tdst += 64 * K;
+    hook(sub);
   }
   if (PERSIST) {
     st_coherent(wrH + Tb + 1 + lane, obH);
@@ -398,10 +413,12 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_tile(const FillArgs 
     if (Tb < 0) continue;
     if (Tb >= a.n + 63) break;
     const bool interior = !DUMP && (Tb >= 64) && (Tb + 63 < a.n);
+    int ibH, ibF, yb;
+    load_block_inputs<KIND, K, FLAGS>(a, s, Tb, lane, ibH, ibF, yb);
     if (interior)
-      run_block<KIND, K, false, FLAGS>(st, a, s, Tb, lane, ldsLane, xr, dprow);
+      run_block<KIND, K, false, FLAGS>(st, a, s, Tb, lane, ldsLane, xr, dprow, ibH, ibF, yb, NoHook());
     else
-      run_block<KIND, K, true, FLAGS>(st, a, s, Tb, lane, ldsLane, xr, dprow);
+      run_block<KIND, K, true, FLAGS>(st, a, s, Tb, lane, ldsLane, xr, dprow, ibH, ibF, yb, NoHook());
   }
 
   if (q == qmax) {
@@ -474,30 +491,84 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
 #pragma unroll
       for (int k = 0; k < K; ++k) st.Hg[k] = add_gap<(FLAGS & FLAG_FRAC) != 0>(st.H[k], a.go, a.fo) + 1;
     }
+    // Block loop.  Everything with memory latency is taken off the critical path:
+    //  * the progress word of strip s-1 is polled after sub-block 1 of the CURRENT block and looked
+    //    at after sub-block 2; if it already covers the next block, that block's inputs are loaded
+    //    right there (behind the poll, as the hand-off protocol requires) and arrive while
+    //    sub-block 3 computes; only a strip that has caught up with its predecessor takes the
+    //    blocking path at the top;
+    //  * the completion of block b-1 is published after sub-block 0 of block b, behind a counted
+    //    vmcnt that leaves only the trace stores just issued in flight, instead of draining the
+    //    store queue at every block end.
     bool dead = false;
+    int seen = 0;            // blocks strip s-1 is known to have published
+    bool have_next = false;  // inputs of the next block already in nH/nF/ny
+    int nH = 0, nF = 0, ny = 0;
+    int* const my_prog = a.prog + s;
+    const int* const up_prog = a.prog + (s > 0 ? s - 1 : 0);
 #pragma unroll 1
     for (int b = 0; b < NB; ++b) {
       const int Tb = 64 * b;
-      if (s > 0) {
-        const int need = min(b + 2, NB);
-        int spins = 0;
-        while (ld_coherent(a.prog + (s - 1)) < need) {
-          __builtin_amdgcn_s_sleep(2);
-          if (++spins > a.spin_limit || ((spins & 255) == 0 && ld_coherent(a.err) != 0)) {
-            dead = true;
-            break;
+      int ibH, ibF, yb;
+      if (have_next) {
+        ibH = nH;
+        ibF = nF;
+        yb = ny;
+      } else {
+        if (s > 0) {
+          const int need = min(b + 2, NB);
+          int spins = 0;
+          while (seen < need) {
+            seen = ld_coherent(up_prog);
+            if (seen >= need) break;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > a.spin_limit || ((spins & 255) == 0 && ld_coherent(a.err) != 0)) {
+              dead = true;
+              break;
+            }
+          }
+          if (dead) break;
+          asm volatile("" ::: "memory");  // data loads stay behind the poll
+        }
+        load_block_inputs<KIND, K, PF>(a, s, Tb, lane, ibH, ibF, yb);
+      }
+      have_next = false;
+      int pv = 0;
+      bool polled = false;
+      auto hook = [&](int sub) {
+        if (sub == 0) {
+          if (b > 0) {
+            // blocks 0..b-1 are complete once everything older than this sub-block's trace
+            // stores has retired (vmcnt counts loads and stores together, in issue order)
+            if (K == 8)
+              asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else
+              asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+            if (lane == 0) st_coherent(my_prog, b);
+          }
+        } else if (sub == 1) {
+          if (s > 0 && b + 1 < NB && seen < min(b + 3, NB)) {
+            pv = ld_coherent(up_prog);
+            polled = true;
+          }
+        } else if (sub == 2) {
+          if (polled) seen = max(seen, pv);
+          if (b + 1 < NB && (s == 0 || seen >= min(b + 3, NB))) {
+            asm volatile("" ::: "memory");
+            load_block_inputs<KIND, K, PF>(a, s, Tb + 64, lane, nH, nF, ny);
+            have_next = true;
           }
         }
-        if (dead) break;
-        asm volatile("" ::: "memory");  // data loads stay behind the poll
-      }
+      };
       const bool interior = (Tb >= 64) && (Tb + 63 < a.n);
       if (interior)
-        run_block<KIND, K, false, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow);
+        run_block<KIND, K, false, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow, ibH, ibF, yb, hook);
       else
-        run_block<KIND, K, true, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's stores have completed
-      if (lane == 0) st_coherent(a.prog + s, b + 1);
+        run_block<KIND, K, true, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow, ibH, ibF, yb, hook);
+    }
+    if (!dead) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last block's stores have completed
+      if (lane == 0) st_coherent(my_prog, NB);
     }
     if (dead) {
       if (lane == 0) st_coherent(a.err, 1);
