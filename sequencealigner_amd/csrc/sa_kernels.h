@@ -648,6 +648,43 @@ __device__ __forceinline__ uint32_t trace_code(const uint32_t* __restrict__ trac
   return tagged ? (raw == 3u ? 3u : 2u - raw) : raw;
 }
 
+// A 64-row window of codes held in registers: lane d keeps three consecutive trace dwords (48
+// skewed steps) of matrix row i-d, centred on the cell the pure diagonal through the entry cell
+// would visit.  The path is then followed through all 64 rows without touching memory; an offset
+// `o` (left moves shift it by -1, up moves by +1) says how far the path has drifted from that
+// diagonal, and 48 positions tolerate |o| <= 16.
+struct TraceWindow {
+  uint32_t w0, w1, w2;
+  int pb;  // position of the diagonal cell inside the 48-position window (16..31)
+};
+
+__device__ __forceinline__ TraceWindow load_trace_window(const uint32_t* __restrict__ trace, int i, int j0, int d, int lgK, int W) {
+  const int r = i - d - 1, c = j0 - d - 1;
+  const int g = r >> lgK, k = r & ((1 << lgK) - 1);
+  const int s = g >> 6, l = g & 63;
+  const int t = c + l;
+  const int wi = t >> 4;
+  const size_t base = ((size_t)s * W * 64 + l) << lgK;
+  const size_t stride = (size_t)64 << lgK;
+  TraceWindow w;
+  w.w0 = trace[base + (size_t)(wi - 1) * stride + k];
+  w.w1 = trace[base + (size_t)wi * stride + k];
+  w.w2 = trace[base + (size_t)min(wi + 1, W - 1) * stride + k];
+  w.pb = 16 + (t & 15);
+  return w;
+}
+
+// op code (0 diag, 1 left, 2 up, 3 stop) at window position q, 4 if q is outside the window
+__device__ __forceinline__ uint32_t window_code(const TraceWindow& w, int q, bool tagged) {
+  const uint32_t dw = q < 16 ? w.w0 : (q < 32 ? w.w1 : w.w2);
+  const uint32_t raw = (dw >> (2 * (q & 15))) & 3u;
+  const uint32_t op = tagged ? (raw == 3u ? 3u : 2u - raw) : raw;
+  return (q >= 0 && q < 48) ? op : 4u;
+}
+
+// the window path needs 64 rows above and room for 16 columns of drift on both sides
+__device__ __forceinline__ bool window_ok(int i, int j) { return i >= 64 && j >= 81; }
+
 __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
   const int d = threadIdx.x;
   const bool tagged = a.kind != KIND_LCS;
@@ -672,15 +709,73 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
   }
   long long nops = 0;
   uint32_t warm = 0;
-  while (i > 0 && j > 0) {
+  bool have_next = false;  // nw holds the window of entry cell (pi, pj)
+  int pi = 0, pj = 0;
+  TraceWindow nw{0, 0, 0, 0};
+  bool stopped = false;
+  while (i > 0 && j > 0 && !stopped) {
+    if (window_ok(i, j)) {
+      // ---- fast path: 64 rows per memory round trip, the next window already in flight ----
+      TraceWindow w;
+      int j0, o;
+      if (have_next && pi == i && abs(j - pj) <= 14) {
+        w = nw;
+        j0 = pj;
+        o = j - pj;
+      } else {
+        w = load_trace_window(a.trace, i, j, d, lgK, a.W);
+        j0 = j;
+        o = 0;
+      }
+      have_next = window_ok(i - 64, j - 64);
+      if (have_next) {
+        pi = i - 64;
+        pj = j - 64;
+        nw = load_trace_window(a.trace, pi, pj, d, lgK, a.W);
+      }
+      int dcur = 0;
+      const int o_in = o;
+      while (dcur < 64) {
+        const uint32_t cM = window_code(w, w.pb + o, tagged);
+        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cM, dcur);
+        if (c0 == 4u) break;  // drifted out of the window: re-centre
+        if (c0 == 3u) {       // SW stop cell
+          stopped = true;
+          break;
+        }
+        int L = 1;
+        if (c0 == 0u) {
+          const unsigned long long run = __ballot(cM == 0u) >> dcur;
+          L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);
+        } else if (c0 == 2u) {
+          const uint32_t cF = window_code(w, w.pb + o + (d - dcur), tagged);
+          const unsigned long long run = __ballot(cF == 2u) >> dcur;
+          L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);
+        }
+        if (c0 == 1u) {
+          if (d == 0) a.ops[nops] = 1;
+          o -= 1;
+        } else {
+          if (d >= dcur && d < dcur + L) a.ops[nops + (d - dcur)] = (uint8_t)c0;
+          dcur += L;
+          if (c0 == 2u) o += L;
+        }
+        nops += L;
+      }
+      if (dcur == 0 && o == o_in && !stopped) {
+        have_next = false;  // no progress possible from this window (cannot happen with |o| <= 14)
+      }
+      i -= dcur;
+      j = j0 - dcur + o;
+      if (dcur != 0 || o != o_in || stopped) continue;
+    }
+    // ---- generic path (borders, SW tails, tiny matrices): one run per memory round trip ----
     const bool vM = (i - d >= 1) && (j - d >= 1);
     const bool vE = (j - d >= 1);
     const bool vF = (i - d >= 1);
     const uint32_t cM = vM ? trace_code(a.trace, i - d, j - d, lgK, a.W, tagged) : 3u;
     const uint32_t cE = vE ? trace_code(a.trace, i, j - d, lgK, a.W, tagged) : 3u;
     const uint32_t cF = vF ? trace_code(a.trace, i - d, j, lgK, a.W, tagged) : 3u;
-    // touch the next 64 cells of this diagonal so the following iteration finds them in L2
-    if (i - d - 64 >= 1 && j - d - 64 >= 1) warm += trace_code(a.trace, i - d - 64, j - d - 64, lgK, a.W, tagged);
     const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cM);
     if (c0 == 3u) break;  // SW stop cell ('X', main.cpp:1233)
     unsigned long long run;
