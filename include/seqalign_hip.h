@@ -158,6 +158,17 @@ typedef struct {
   int64_t chunk_rows;
   sa_stripe_event_fn on_event;
   void* user;
+  /* Optional (both NULL = the launch-per-diagonal schedule above, transfers on the ctx stream):
+   * hipStream_t of the caller's receive and send streams.  When given (and the configuration
+   * allows the persistent pipeline: integral gaps, chunk_rows a multiple of 512) the stripe is ONE
+   * persistent launch on the ctx stream and the border crosses while it runs: the library calls
+   * SA_EV_NEED_LEFT(k) for every chunk right away -- the caller enqueues the receive of chunk k on
+   * stream_in, the library follows it with a one-wave kernel that tells the running fill the rows
+   * are there -- and SA_EV_RIGHT_READY(k) after enqueueing, on stream_out, a one-wave kernel that
+   * returns when the fill has written chunk k of `right`; the caller enqueues the send of chunk k
+   * on stream_out.  Neither stream may be the ctx stream. */
+  void* stream_in;
+  void* stream_out;
 } sa_stripe_desc;
 
 int sa_stripe_fill(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m, const uint8_t* y_stripe, int64_t n_stripe,

@@ -64,6 +64,10 @@ struct FillArgs {
   int* ticket;           // next strip to hand out (zeroed)
   int* err;              // set to 1 when a bounded spin ran out (zeroed)
   int spin_limit;        // polls before a waiting wave gives up
+  // persistent pipeline over column stripes: borders cross GPUs while the kernel runs
+  const int* rows_in;    // rows of `lb` that have arrived (raised by stripe_signal on the receive stream); null: all there
+  int* chunk_done;       // [chunks] strips of border chunk k whose `rb` rows are written (stripe_wait polls it); null: no right neighbour
+  int strips_per_chunk;
 };
 
 // Inter-wave hand-off of the strip bottom rows inside ONE launch (persistent kernel only).
@@ -85,6 +89,10 @@ __device__ __forceinline__ int dpp_shl1(int old, int src) {  // lane l <- src of
 __device__ __forceinline__ int dpp_shl1_any(int src) { return __builtin_amdgcn_mov_dpp(src, 0x130, 0xf, 0xf, false); }
 
 enum { FLAG_FRAC = 1, FLAG_DUMP = 2, FLAG_PERSIST = 4 };
+#ifndef SA_SUB_UNROLL
+#define SA_SUB_UNROLL 4
+#endif
+constexpr int kSubUnroll = SA_SUB_UNROLL;  // 16-step sub-blocks of a 64-step block expanded in line
 
 // Workgroups are 4 independent waves (256 threads): the hardware places the 4 waves of one
 // workgroup on the 4 SIMDs of a CU, which single-wave workgroups do not guarantee -- and a wave
@@ -242,7 +250,8 @@ __device__ __forceinline__ void store_trace(uint32_t* dst, const uint32_t (&t)[K
 
 // loads of one block's inputs: the 64 bottom-row entries of the strip above (in-buffers) and the
 // 64 target symbols lane 0 will consume
-template <int KIND, int K, int FLAGS>
+// RAW_Y: leave the symbol unscaled, so that nothing touches the loaded registers before use
+template <int KIND, int K, int FLAGS, bool RAW_Y = false>
 __device__ __forceinline__ void load_block_inputs(const FillArgs& a, const int s, const int Tb, const int lane, int& ibH,
                                                   int& ibF, int& yb) {
   using G = Geo<KIND, K>;
@@ -258,7 +267,7 @@ __device__ __forceinline__ void load_block_inputs(const FillArgs& a, const int s
     if (KIND != KIND_LCS) ibF = rdF[Tb + 64 + lane];
   }
   yb = a.yenc[Tb + lane];
-  if (KIND != KIND_LCS) yb *= G::ROWB;
+  if (KIND != KIND_LCS && !RAW_Y) yb *= G::ROWB;
 }
 
 struct NoHook {
@@ -272,11 +281,16 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
                                           const int lane, const char* ldsLane, const uint32_t (&xr)[K], int* dprow,
                                           int ibH, int ibF, int yb, Hook&& hook) {
   constexpr bool PERSIST = (FLAGS & FLAG_PERSIST) != 0;
+  // The persistent NW / LCS kernels expand the four sub-blocks in line: values prefetched in one
+  // sub-block and used in a later one then stay in their registers (a loop makes them
+  // loop-carried copies, and the compiler waits for a load before it copies its result).  The SW
+  // body is too large for that (it spills), so it keeps the loop.
+  constexpr int kUnroll = (PERSIST && KIND != KIND_SW) ? kSubUnroll : 1;
   int* wrH = a.botH + (size_t)(s & 1) * a.NP;
   int* wrF = a.botF + (size_t)(s & 1) * a.NP;
   int obH = 0, obF = 0;
   uint32_t* tdst = a.trace + (((size_t)s * a.W + (Tb >> 4)) * 64 + lane) * K;
-#pragma unroll 1
+#pragma unroll kUnroll
   for (int sub = 0; sub < 4; ++sub) {
     uint32_t tacc[K];
 #pragma unroll
@@ -300,12 +314,15 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
 
 // lane state at the first column of a strip, from the left border (values of matrix column 0 of
 // this stripe); NW / SW registers hold 4*score (+ tag)
+// coh: the border arrived from another GPU while this kernel was running (sc1 loads)
 template <int KIND, int K, int FLAGS>
-__device__ __forceinline__ void strip_begin(Lane<KIND, K>& st, const FillArgs& a, const int r0) {
+__device__ __forceinline__ void strip_begin(Lane<KIND, K>& st, const FillArgs& a, const int r0, const bool coh = false) {
   constexpr int SH = (KIND == KIND_LCS) ? 0 : 2;
+  const int* lbi = reinterpret_cast<const int*>(a.lb);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
-    const int2 b = a.lb[min(r0 + k + 1, a.m)];
+    const int row = min(r0 + k + 1, a.m);
+    const int2 b = coh ? make_int2(ld_coherent(lbi + 2 * row), ld_coherent(lbi + 2 * row + 1)) : a.lb[row];
     st.H[k] = b.x * (1 << SH);
     st.E[k] = (KIND == KIND_LCS) ? b.y : b.y * (1 << SH) + 1;
     st.best[k] = 0;
@@ -314,7 +331,7 @@ __device__ __forceinline__ void strip_begin(Lane<KIND, K>& st, const FillArgs& a
   st.passH = st.H[K - 1];
   st.passF = (KIND == KIND_NW) ? kNeg : 0;
   st.ypass = 0;
-  st.dprev = a.lb[min(r0, a.m)].x * (1 << SH);
+  st.dprev = (coh ? ld_coherent(lbi + 2 * min(r0, a.m)) : a.lb[min(r0, a.m)].x) * (1 << SH);
 }
 
 // outputs of a finished strip: right border (column stripes), SW row bests, the final score
@@ -324,7 +341,15 @@ __device__ __forceinline__ void strip_end(const Lane<KIND, K>& st, const FillArg
   if (a.rb) {  // the lane's rows froze at the stripe's last column
 #pragma unroll
     for (int k = 0; k < K; ++k)
-      if (r0 + k < a.m) a.rb[r0 + k + 1] = make_int2(st.H[k] >> SH, st.E[k] >> SH);
+      if (r0 + k < a.m) {
+        if (a.chunk_done) {  // read by a send that starts while this kernel is still running
+          int* o = reinterpret_cast<int*>(a.rb + r0 + k + 1);
+          st_coherent(o, st.H[k] >> SH);
+          st_coherent(o + 1, st.E[k] >> SH);
+        } else {
+          a.rb[r0 + k + 1] = make_int2(st.H[k] >> SH, st.E[k] >> SH);
+        }
+      }
   }
   if (KIND == KIND_SW) {
 #pragma unroll
@@ -485,8 +510,25 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
       for (int i = lane; i < a.alpha * 64 * G::PW; i += 64) lds[i] = gp[i];
       wave_lds_fence();
     }
+    bool dead = false;
+    if (a.rows_in) {  // column stripes: the strip's rows of the left border must have arrived
+      const int need = min(a.m, (s + 1) * 64 * K);
+      int spins = 0;
+      while (ld_coherent(a.rows_in) < need) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++spins > a.spin_limit || ((spins & 255) == 0 && ld_coherent(a.err) != 0)) {
+          dead = true;
+          break;
+        }
+      }
+      if (dead) {
+        if (lane == 0) st_coherent(a.err, 1);
+        break;
+      }
+      asm volatile("" ::: "memory");  // border loads stay behind the poll
+    }
     Lane<KIND, K> st;
-    strip_begin<KIND, K, FLAGS>(st, a, r0);
+    strip_begin<KIND, K, FLAGS>(st, a, r0, a.rows_in != nullptr);
     if (KIND != KIND_LCS) {
 #pragma unroll
       for (int k = 0; k < K; ++k) st.Hg[k] = add_gap<(FLAGS & FLAG_FRAC) != 0>(st.H[k], a.go, a.fo) + 1;
@@ -500,10 +542,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
     //  * the completion of block b-1 is published after sub-block 0 of block b, behind a counted
     //    vmcnt that leaves only the trace stores just issued in flight, instead of draining the
     //    store queue at every block end.
-    bool dead = false;
     int seen = 0;            // blocks strip s-1 is known to have published
     bool have_next = false;  // inputs of the next block already in nH/nF/ny
     int nH = 0, nF = 0, ny = 0;
+    int vzero;  // 0 in a VGPR the compiler cannot see through
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     int* const my_prog = a.prog + s;
     const int* const up_prog = a.prog + (s > 0 ? s - 1 : 0);
 #pragma unroll 1
@@ -513,7 +556,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
       if (have_next) {
         ibH = nH;
         ibF = nF;
-        yb = ny;
+        yb = (KIND != KIND_LCS) ? ny * G::ROWB : ny;
       } else {
         if (s > 0) {
           const int need = min(b + 2, NB);
@@ -534,7 +577,6 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
       }
       have_next = false;
       int pv = 0;
-      bool polled = false;
       auto hook = [&](int sub) {
         if (sub == 0) {
           if (b > 0) {
@@ -547,15 +589,15 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
             if (lane == 0) st_coherent(my_prog, b);
           }
         } else if (sub == 1) {
-          if (s > 0 && b + 1 < NB && seen < min(b + 3, NB)) {
-            pv = ld_coherent(up_prog);
-            polled = true;
-          }
+          // Unconditional, and a per-lane load: a poll that is issued on some paths only, or whose
+          // result has to sit in an SGPR, makes the compiler wait for it (and for everything
+          // issued before it) much earlier than it is needed.
+          pv = ld_coherent(up_prog + vzero);
         } else if (sub == 2) {
-          if (polled) seen = max(seen, pv);
+          seen = max(seen, __builtin_amdgcn_readfirstlane(pv));
           if (b + 1 < NB && (s == 0 || seen >= min(b + 3, NB))) {
             asm volatile("" ::: "memory");
-            load_block_inputs<KIND, K, PF>(a, s, Tb + 64, lane, nH, nF, ny);
+            load_block_inputs<KIND, K, PF, true>(a, s, Tb + 64, lane, nH, nF, ny);
             have_next = true;
           }
         }
@@ -575,6 +617,31 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
       break;
     }
     strip_end<KIND, K>(st, a, s, rowg, r0);
+    if (a.chunk_done) {  // the strip's right-border rows are out: count it into its chunk
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(a.chunk_done + s / a.strips_per_chunk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// Column stripes with the persistent kernel: the two ends of a border hand-off, each a one-wave
+// kernel on the caller's receive / send stream, so that RCCL transfers overlap the running fill.
+// stripe_signal follows the receive of chunk k in stream order and raises rows_in;
+// stripe_wait precedes the send of chunk k and returns once all strips of the chunk have counted
+// themselves into chunk_done[k] (bounded; raises *err when it gives up).
+__global__ void stripe_signal(int* rows_in, int rows) {
+  if (threadIdx.x == 0) st_coherent(rows_in, rows);
+}
+__global__ void stripe_wait(const int* cnt, int target, int* err, int spin_limit) {
+  if (threadIdx.x != 0) return;
+  int spins = 0;
+  while (ld_coherent(cnt) < target) {
+    __builtin_amdgcn_s_sleep(32);
+    if (++spins > spin_limit) {
+      st_coherent(err, 1);
+      break;
+    }
+    if ((spins & 63) == 0 && ld_coherent(err) != 0) break;
   }
 }
 

@@ -35,7 +35,7 @@ struct sa_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [4]: stripe flags reset
   std::string err;
   int force_K = 0, force_C = 0;
   int persist = 1;  // 1: persistent strip pipeline (one launch) where it applies
@@ -132,6 +132,38 @@ Tuning choose_tuning(const sa_ctx* ctx, int kind, int64_t m, int64_t n, int64_t 
   return t;
 }
 
+// Rows per lane for the persistent pipeline over column stripes.  Every rank evaluates the same
+// model of the LAST stripe's finishing time and so picks the same K: its first strip can start
+// once each stripe to its left has emitted its first border chunk (T_first each), then it works
+// through its own strips, ceil(S / resident waves) rounds of one sweep each, plus the ramp of the
+// strip chain (consecutive strips run 128 steps apart).  A large K is the cheapest per cell but the
+// slowest per step, so the more GPUs share the columns, the smaller K gets.  Step costs measured
+// on MI355X (tools/perf_stripe_model.py): (10 K + 18) issue slots of 4 cycles for NW.
+// R > 0: K must divide the border chunk into whole strips.
+int choose_stripe_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n, int64_t n_total, int64_t R) {
+  const double cell = kind == KIND_LCS ? 7.0 : (kind == KIND_SW ? 13.0 : 10.0);
+  const double step0 = 18.0;
+  const double waves = 4.0 * ctx->n_cu * std::max(1, ctx->wps);
+  double best = 1e300;
+  int bestK = 0;
+  for (int K : {1, 2, 4, 8}) {
+    if (R > 0 && R % (64 * K) != 0) continue;
+    if (ctx->force_K && K != ctx->force_K) continue;
+    const double step = (cell * K + step0) * 4.0;
+    const double S = std::ceil((double)m / (64.0 * K));
+    const double hops = n > 0 ? std::max(0.0, std::round((double)n_total / (double)n) - 1.0) : 0.0;
+    const double first = ((double)n + (R > 0 ? (double)R / (64.0 * K) : 1.0) * 128.0) * step;
+    const double own = std::ceil(S / waves) * ((double)n + 63.0) * step;
+    const double ramp = std::min(S, waves) * 128.0 * step;
+    const double est = hops * first + own + ramp;
+    if (est < best) {
+      best = est;
+      bestK = K;
+    }
+  }
+  return bestK ? bestK : 1;
+}
+
 template <int KIND>
 void launch_fill(int K, int fl, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a) {
   // instantiated combinations: plain K in {1,2,4,8}; FRAC only with K=2; DUMP (+FRAC) only with K=1
@@ -225,6 +257,7 @@ struct StripeDesc {  // internal mirror of sa_stripe_desc; all-null = the whole 
   int64_t chunk_rows = 0;
   sa_stripe_event_fn on_event = nullptr;
   void* user = nullptr;
+  hipStream_t stream_in = nullptr, stream_out = nullptr;
 };
 
 int check_scoring(sa_ctx* ctx, int kind, const sa_scoring* sc, int64_t m, int64_t n_total) {
@@ -258,12 +291,23 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   }
   const int fl = ((fo || fe) ? FLAG_FRAC : 0) | (dump ? FLAG_DUMP : 0);
   Tuning tun = choose_tuning(ctx, kind, m, n, sd ? sd->col_begin : 0);
-  // persistent strip pipeline: whole matrix on this GPU, plain integral configuration
-  const bool persist = ctx->persist && fl == 0 && (!sd || (sd->is_first && sd->is_last));
+  // column stripes: border chunk k = matrix rows k*R+1 .. min(m,(k+1)*R)
+  const bool ev_in = sd && !sd->is_first && sd->on_event;
+  const bool ev_out = sd && !sd->is_last && sd->on_event;
+  const int64_t R = sd ? std::max<int64_t>(sd->chunk_rows, 1) : 0;
+  const int64_t n_chunks = sd ? (m + R - 1) / R : 0;
+  // persistent strip pipeline: plain integral configuration; over column stripes the borders
+  // must be able to cross while the kernel runs (the caller's two transfer streams)
+  const bool striped = sd && !(sd->is_first && sd->is_last);
+  const bool persist = ctx->persist && fl == 0 &&
+                       (!striped || ((!ev_in || sd->stream_in) && (!ev_out || (sd->stream_out && R % 64 == 0))));
   if (fl & FLAG_DUMP) {
     tun.K = 1, tun.C = 64;
   } else if (fl & FLAG_FRAC) {
     tun.K = 2;
+  } else if (persist && striped) {
+    tun.K = choose_stripe_K(ctx, kind, m, n, sd->n_total, ev_out ? R : 0);
+    tun.C = 64;
   } else if (persist) {
     // as many rows per lane as still leave every SIMD a strip of its own
     tun.K = 1;
@@ -294,7 +338,8 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   if ((rc = ensure(ctx, ctx->bot, (size_t)4 * NP * 4))) return rc;
   if ((rc = ensure(ctx, ctx->state, (size_t)S * NF * 64 * 4))) return rc;
   if ((rc = ensure(ctx, ctx->small, 256))) return rc;
-  if (persist && (rc = ensure(ctx, ctx->pbuf, ((size_t)S + 64) * 4))) return rc;
+  const size_t pbuf_ints = (size_t)S + 64 + (size_t)n_chunks;
+  if (persist && (rc = ensure(ctx, ctx->pbuf, pbuf_ints * 4))) return rc;
   if ((rc = ensure(ctx, ctx->ops, (size_t)m + n + 64))) return rc;
   if (kind != KIND_LCS) {
     if ((rc = ensure(ctx, ctx->prof, (size_t)S * alpha * 64 * PW * 4))) return rc;
@@ -389,19 +434,25 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   auto f_lo = [&](int s) { return (long long)s + (64LL * s) / C; };
   auto f_hi = [&](int s) { return (long long)s + (64LL * s + n + 62) / C; };
   const long long dmax = f_hi(S - 1);
-  // column stripes: border chunk k = matrix rows k*R+1 .. min(m,(k+1)*R)
-  const bool ev_in = sd && !sd->is_first && sd->on_event;
-  const bool ev_out = sd && !sd->is_last && sd->on_event;
-  const int64_t R = sd ? std::max<int64_t>(sd->chunk_rows, 1) : 0;
-  const int64_t n_chunks = sd ? (m + R - 1) / R : 0;
   int64_t chunks_in = 0, chunks_out = 0;
   int slo = 0, shi = -1, launches = 0;
   if (persist) {
-    HIPCK(ctx, hipMemsetAsync(ctx->pbuf.p, 0, ((size_t)S + 64) * 4, st));
+    HIPCK(ctx, hipMemsetAsync(ctx->pbuf.p, 0, pbuf_ints * 4, st));
     a.prog = (int*)ctx->pbuf.p + 64;
     a.ticket = (int*)ctx->pbuf.p;
     a.err = (int*)ctx->small.p + 40;  // byte 160 of the small block, read back with the score
     a.spin_limit = 1 << 22;
+    if (striped && ev_in) a.rows_in = (int*)ctx->pbuf.p + 32;
+    if (striped && ev_out) {
+      a.chunk_done = (int*)ctx->pbuf.p + 64 + S;
+      a.strips_per_chunk = (int)(R / (64 * K));
+    }
+    if (a.rows_in || a.chunk_done) {
+      // the transfer streams may not touch the flags before they are reset
+      HIPCK(ctx, hipEventRecord(ctx->ev[4], st));
+      if (a.rows_in) HIPCK(ctx, hipStreamWaitEvent(sd->stream_in, ctx->ev[4], 0));
+      if (a.chunk_done) HIPCK(ctx, hipStreamWaitEvent(sd->stream_out, ctx->ev[4], 0));
+    }
   }
   HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
   if (persist) {
@@ -413,6 +464,18 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
     else
       launch_persistent<KIND_LCS>(K, grid, lds, st, a);
     launches = 1;
+    // border hand-offs, all enqueued now and resolved on the device while the fill runs
+    for (int64_t k = 0; k < n_chunks && (a.rows_in || a.chunk_done); ++k) {
+      if (a.rows_in) {
+        if (sd->on_event(sd->user, SA_EV_NEED_LEFT, k)) return fail(ctx, SA_ERR_ARG, "stripe callback failed (need chunk %lld)", (long long)k);
+        hipLaunchKernelGGL(stripe_signal, dim3(1), dim3(64), 0, sd->stream_in, (int*)a.rows_in, (int)std::min<int64_t>(m, (k + 1) * R));
+      }
+      if (a.chunk_done) {
+        const int target = (int)(std::min<int64_t>(S, (k + 1) * a.strips_per_chunk) - k * a.strips_per_chunk);
+        hipLaunchKernelGGL(stripe_wait, dim3(1), dim3(64), 0, sd->stream_out, a.chunk_done + k, target, a.err, 1 << 22);
+        if (sd->on_event(sd->user, SA_EV_RIGHT_READY, k)) return fail(ctx, SA_ERR_ARG, "stripe callback failed (ready chunk %lld)", (long long)k);
+      }
+    }
   }
   for (long long d = 0; !persist && d <= dmax; ++d) {
     while (shi + 1 < S && f_lo(shi + 1) <= d) ++shi;
@@ -621,10 +684,19 @@ int run_stripe_fill(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const 
   sd.chunk_rows = d->chunk_rows;
   sd.on_event = d->on_event;
   sd.user = d->user;
+  sd.stream_in = (hipStream_t)d->stream_in;
+  sd.stream_out = (hipStream_t)d->stream_out;
+  if ((sd.stream_in && sd.stream_in == ctx->stream) || (sd.stream_out && sd.stream_out == ctx->stream))
+    return fail(ctx, SA_ERR_ARG, "stream_in / stream_out must differ from the ctx stream");
   if ((rc = fill_impl(ctx, kind, x, m, y, n, sc, &sd, 0, out, rowb, colb))) return rc;
-  int h_score = 0;
-  HIPCK(ctx, hipMemcpyAsync(&h_score, ctx->small.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  int h_small[41] = {0};  // [0] score, [40] persistent-kernel error flag
+  HIPCK(ctx, hipMemcpyAsync(h_small, ctx->small.p, sizeof h_small, hipMemcpyDeviceToHost, ctx->stream));
   HIPCK(ctx, hipStreamSynchronize(ctx->stream));
+  if (h_small[40] != 0) {
+    ctx->last.valid = 0;
+    return fail(ctx, SA_ERR_HIP, "persistent stripe fill: a bounded wait (previous strip / left border / border send) expired");
+  }
+  const int h_score = h_small[0];
   float t01 = 0, t12 = 0;
   HIPCK(ctx, hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]));
   HIPCK(ctx, hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]));

@@ -85,6 +85,8 @@ class _StripeDesc(C.Structure):
         ("chunk_rows", C.c_int64),
         ("on_event", STRIPE_EVENT_FN),
         ("user", C.c_void_p),
+        ("stream_in", C.c_void_p),
+        ("stream_out", C.c_void_p),
     ]
 
 
@@ -251,7 +253,7 @@ class Engine:
 
     # ---- column stripes (one process per GPU; the caller moves the border chunks) ----------
     def stripe_fill(self, kind, x, y_stripe, n_total, col_begin, is_first, is_last, left_ptr, right_ptr, chunk_rows,
-                    on_event, mode="dna", gap_open=-5.0, gap_extend=-1.0) -> AlignResult:
+                    on_event, mode="dna", gap_open=-5.0, gap_extend=-1.0, stream_in=None, stream_out=None) -> AlignResult:
         """on_event(event, chunk) -> None is called while the fill is being enqueued (see
         include/seqalign_hip.h); left_ptr / right_ptr are device addresses of int32[m+1][2]."""
         x, y = _u8(x), _u8(y_stripe)
@@ -267,7 +269,8 @@ class Engine:
                 return 1
 
         cb = STRIPE_EVENT_FN(_cb)
-        d = _StripeDesc(int(n_total), int(col_begin), int(is_first), int(is_last), left_ptr, right_ptr, int(chunk_rows), cb, None)
+        d = _StripeDesc(int(n_total), int(col_begin), int(is_first), int(is_last), left_ptr, right_ptr, int(chunk_rows), cb, None,
+                        stream_in, stream_out)
         r = _Result()
         rc = self.lib.sa_stripe_fill(self.ctx, KINDS[kind], x.ctypes.data, len(x), y.ctypes.data, len(y), C.byref(sc),
                                      C.byref(d), C.byref(r))

@@ -8,6 +8,12 @@ tests): nearest-neighbour point-to-point only, no collective on the data path.  
 runs right to left, each rank walking its own codes and handing the exit row to its left
 neighbour; rank 0 concatenates the op lists.
 
+On the GPU the stripe is ONE persistent launch and the border crosses while it runs: receives are
+enqueued on a receive stream, sends on a send stream, and the library brackets them with one-wave
+signal / wait kernels (include/seqalign_hip.h, sa_stripe_desc.stream_in / stream_out).  The two links
+of a rank (to its left and to its right neighbour) use two different process groups, so that the
+transfers of one never queue behind the other inside the backend.
+
 The engine is duck-typed (stripe_fill / stripe_traceback / alloc_border) so that the same
 orchestration is exercised on CPU by the tests with an oracle-backed engine.
 """
@@ -37,6 +43,19 @@ class GpuStripeEngine:
         # the ctx's own stream" -- and then the kernels would not be ordered with RCCL's send/recv.
         self.stream = torch.cuda.Stream(device=self.device)
         self.eng.set_stream(self.stream.cuda_stream)
+        # border transfers overlap the running fill: receives on one stream, sends on another
+        self.stream_in = torch.cuda.Stream(device=self.device)
+        self.stream_out = torch.cuda.Stream(device=self.device)
+
+    def transfer_context(self, incoming: bool):
+        return self.torch.cuda.stream(self.stream_in if incoming else self.stream_out)
+
+    def transfer_streams(self):
+        return self.stream_in.cuda_stream, self.stream_out.cuda_stream
+
+    def sync_transfers(self):
+        self.stream_in.synchronize()
+        self.stream_out.synchronize()
 
     def stream_context(self):
         return self.torch.cuda.stream(self.stream)
@@ -63,12 +82,47 @@ class GpuStripeEngine:
         return self.eng.lcs(x, y) if kind == "lcs" else getattr(self.eng, kind)(x, y, mode, go, ge)
 
 
+class StripeError(RuntimeError):
+    """some rank's stripe fill failed (raised on every rank)"""
+
+
 class StripedAligner:
-    def __init__(self, local_rank, rank, world, dist, engine=None, chunk_rows=8192, min_stripe_cols=256):
+    def __init__(self, local_rank, rank, world, dist, engine=None, chunk_rows=8192, min_stripe_cols=256, overlap=True):
         self.rank, self.world, self.dist = rank, world, dist
         self.engine = engine if engine is not None else GpuStripeEngine(local_rank)
         self.chunk_rows = int(chunk_rows)
         self.min_stripe_cols = int(min_stripe_cols)
+        # overlap: persistent fill with the borders crossing on two transfer streams while it runs;
+        # False: the launch-per-diagonal schedule with the transfers in line on the compute stream
+        self.overlap = bool(overlap)
+        # link (g-1, g) uses group g & 1: a rank's two links never share a backend queue
+        self.link_groups = [None, None]
+        if world > 2 and hasattr(dist, "new_group"):
+            self.link_groups = [dist.new_group(list(range(world))), dist.new_group(list(range(world)))]
+        self._warm = False
+
+    def _link(self, right_rank):
+        """process group of the link whose right end is `right_rank`"""
+        return self.link_groups[right_rank & 1]
+
+    def _warm_links(self):
+        """First use of a point-to-point link sets the connection up (for RCCL that can take
+        seconds and synchronise the device): do it before a persistent kernel is waiting on it."""
+        if self._warm:
+            return
+        self._warm = True
+        E, dist, g, G = self.engine, self.dist, self.rank, self.world
+        if not hasattr(E, "transfer_context"):
+            return
+        for incoming in (True, False):
+            with E.transfer_context(incoming):
+                t = E.small([g])
+                grouped = self.link_groups[0] is not None
+                if incoming and g > 0:
+                    dist.recv(t, src=g - 1, **({"group": self._link(g)} if grouped else {}))
+                if not incoming and g < G - 1:
+                    dist.send(t, dst=g + 1, **({"group": self._link(g + 1)} if grouped else {}))
+        E.sync_transfers()
 
     def align(self, kind, x, y, mode="dna", gap_open=-5.0, gap_extend=-1.0) -> AlignResult:
         """Every rank passes the same x and y; every rank returns the score, rank 0 also the
@@ -95,19 +149,42 @@ class StripedAligner:
         right = None if last else E.alloc_border(m)
         R = self.chunk_rows
         sends = []
+        overlapped = self.overlap and hasattr(E, "transfer_context")
+        kw_in = {"group": self._link(g)} if self.link_groups[0] is not None else {}
+        kw_out = {"group": self._link(g + 1)} if self.link_groups[0] is not None else {}
 
         def on_event(event, k):
             lo, hi = k * R + 1, min(m, (k + 1) * R) + 1
-            if event == SA_EV_NEED_LEFT:
-                dist.recv(left[lo:hi], src=g - 1)
-            else:
-                sends.append(dist.isend(right[lo:hi], dst=g + 1))
+            incoming = event == SA_EV_NEED_LEFT
+            with (E.transfer_context(incoming) if overlapped else contextlib.nullcontext()):
+                if incoming:
+                    dist.recv(left[lo:hi], src=g - 1, **kw_in)
+                else:
+                    sends.append(dist.isend(right[lo:hi], dst=g + 1, **kw_out))
 
-        res = E.stripe_fill(kind, x, y[c0:c1], n, c0, first, last,
-                            None if first else left.data_ptr(), None if last else right.data_ptr(), R, on_event,
-                            mode, gap_open, gap_extend)
-        for w in sends:
-            w.wait()
+        extra = {}
+        if overlapped:
+            self._warm_links()
+            E.sync_transfers()  # the border tensors were allocated on the compute stream
+            E.stream.synchronize()
+            extra["stream_in"], extra["stream_out"] = E.transfer_streams()
+        failure = None
+        try:
+            res = E.stripe_fill(kind, x, y[c0:c1], n, c0, first, last,
+                                None if first else left.data_ptr(), None if last else right.data_ptr(), R, on_event,
+                                mode, gap_open, gap_extend, **extra)
+        except RuntimeError as e:  # e.g. a bounded wait inside the persistent kernel expired
+            failure = e
+        with (E.transfer_context(False) if overlapped else contextlib.nullcontext()):
+            for w in sends:
+                w.wait()
+        if overlapped:
+            E.sync_transfers()
+        # everybody learns whether every stripe is good before the traceback chain starts
+        ok = E.small([0 if failure is not None else 1])
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            raise StripeError(f"rank {g}: {failure}" if failure is not None else f"rank {g}: another rank's stripe fill failed")
 
         # traceback, right to left: (exit row) travels g+1 -> g
         if last:

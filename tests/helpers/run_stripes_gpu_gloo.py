@@ -22,14 +22,33 @@ from sequencealigner_amd.synth import dna_pair
 
 
 class GlooForCuda:
-    """send/recv/broadcast of CUDA tensors over gloo by staging through the host."""
+    """send/recv/broadcast of CUDA tensors over gloo by staging through the host.  Like the RCCL
+    backend it moves the data on streams of its own (one per neighbour) that are fenced against
+    the caller's current stream with events, so that the stream / hardware-queue picture of the
+    engine under test is the one it has in production."""
+
+    ReduceOp = dist.ReduceOp
 
     def __init__(self):
-        self.pending = []
+        self.side = {}
+
+    def _side_stream(self, peer):
+        if peer not in self.side:
+            self.side[peer] = torch.cuda.Stream()
+        return self.side[peer]
 
     def recv(self, t, src):
         tmp = torch.empty(t.shape, dtype=t.dtype, device="cpu")
         dist.recv(tmp, src=src)
+        cur, side = torch.cuda.current_stream(), self._side_stream(src)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            t.copy_(tmp)
+        cur.wait_stream(side)
+
+    def all_reduce(self, t, op):
+        tmp = t.cpu()
+        dist.all_reduce(tmp, op=op)
         t.copy_(tmp)
 
     def send(self, t, dst):
@@ -56,9 +75,22 @@ def main():
             r = al.align(kind, x, y, "dna")
             want = orc.lcs(x, y, packed=True) if kind == "lcs" else orc.nw(x, y, "dna", packed=True)
             good = r.score == want.score and (rank != 0 or np.array_equal(r.ops, want.ops))
+            # striped runs take the overlapped schedule: one persistent launch per stripe
+            if n >= 64 * world and r.n_launches != 1:
+                print(f"rank {rank}: {kind} n={n} ran {r.n_launches} launches, expected the persistent pipeline", flush=True)
+                good = False
             if not good:
                 print(f"rank {rank}: MISMATCH {kind} n={n}: {r.score} vs {want.score}", flush=True)
             ok = ok and good
+    # the in-line schedule (launch per tile diagonal, transfers on the compute stream) stays covered
+    al.overlap = False
+    x, y = dna_pair(6000, seed=9, related=True)
+    r = al.align("nw", x, y, "dna")
+    want = orc.nw(x, y, "dna", packed=True)
+    good = r.score == want.score and r.n_launches > 1 and (rank != 0 or np.array_equal(r.ops, want.ops))
+    if not good:
+        print(f"rank {rank}: MISMATCH in-line schedule: {r.score} vs {want.score}, {r.n_launches} launches", flush=True)
+    ok = ok and good
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}: {'GPU_STRIPES_OK' if ok else 'GPU_STRIPES_FAIL'}", flush=True)
