@@ -26,6 +26,13 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
+# Column stripes run one persistent kernel per GPU while RCCL moves the borders on other streams:
+# every stream involved needs a hardware queue of its own (streams that share one are serialised,
+# measured: tools/probe_queue_sharing.py), and HIP's default of 4 queues per process is fewer than
+# the streams of this program + torch + RCCL.  Must be set before the HIP runtime starts.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ["GPU_MAX_HW_QUEUES"] = "16"
+
 import numpy as np
 
 # algorithmic work per cell: int32 VALU lane-ops and HBM bytes

@@ -10,6 +10,8 @@ ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
 sys.path.insert(0, str(ROOT / "tests"))
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -17,7 +19,7 @@ import torch.distributed as dist
 torch.cuda.init()  # before the engine loads its HIP runtime (same order as bench.py)
 
 from oracle import Oracle
-from sequencealigner_amd.stripes import GpuStripeEngine, StripedAligner
+from sequencealigner_amd.stripes import GpuStripeEngine, StripedAligner, StripeError
 from sequencealigner_amd.synth import dna_pair
 
 
@@ -43,7 +45,8 @@ class GlooForCuda:
         cur, side = torch.cuda.current_stream(), self._side_stream(src)
         side.wait_stream(cur)
         with torch.cuda.stream(side):
-            t.copy_(tmp)
+            stage = tmp.to(t.device)  # H2D, then a device-side copy KERNEL on the side stream, as RCCL's
+            t.copy_(stage)            # receive kernel would be: it has to run beside the persistent fill
         cur.wait_stream(side)
 
     def all_reduce(self, t, op):
@@ -69,19 +72,34 @@ def main():
     al = StripedAligner(0, rank, world, GlooForCuda(), engine=GpuStripeEngine(0), chunk_rows=512, min_stripe_cols=64)
     orc = Oracle()
     ok = True
-    for n, seed, rel in [(3000, 1, True), (20000, 2, True), (5000, 3, False), (100, 4, True)]:
+    # EXPECT_FALLBACK=1: the test starved the process of hardware queues (GPU_MAX_HW_QUEUES=1), so the
+    # border transfers cannot run beside the persistent kernel: its bounded waits must expire, every
+    # rank must get a StripeError, and the in-line schedule must then give the right answer.
+    expect_fallback = os.environ.get("EXPECT_FALLBACK") == "1"
+    fell_back = False
+    cases = [(3000, 1, True)] if expect_fallback else [(3000, 1, True), (20000, 2, True), (5000, 3, False), (100, 4, True)]
+    for n, seed, rel in cases:
         x, y = dna_pair(n, seed=seed, related=rel)
         for kind in ("nw", "lcs"):
-            r = al.align(kind, x, y, "dna")
+            try:
+                r = al.align(kind, x, y, "dna")
+            except StripeError as e:
+                print(f"rank {rank}: overlapped schedule failed ({e}); falling back", flush=True)
+                fell_back = True
+                al.overlap = False
+                r = al.align(kind, x, y, "dna")
             want = orc.lcs(x, y, packed=True) if kind == "lcs" else orc.nw(x, y, "dna", packed=True)
             good = r.score == want.score and (rank != 0 or np.array_equal(r.ops, want.ops))
             # striped runs take the overlapped schedule: one persistent launch per stripe
-            if n >= 64 * world and r.n_launches != 1:
+            if n >= 64 * world and r.n_launches != 1 and not fell_back:
                 print(f"rank {rank}: {kind} n={n} ran {r.n_launches} launches, expected the persistent pipeline", flush=True)
                 good = False
             if not good:
                 print(f"rank {rank}: MISMATCH {kind} n={n}: {r.score} vs {want.score}", flush=True)
             ok = ok and good
+    if expect_fallback and not fell_back:
+        print(f"rank {rank}: expected the overlapped schedule to time out with one hardware queue", flush=True)
+        ok = False
     # the in-line schedule (launch per tile diagonal, transfers on the compute stream) stays covered
     al.overlap = False
     x, y = dna_pair(6000, seed=9, related=True)

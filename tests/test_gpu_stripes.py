@@ -102,8 +102,8 @@ def test_stripes_protein_and_gaps(engine, oracle):
         assert score == want.score and np.array_equal(ops, want.ops)
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_striped_aligner_processes_share_one_gpu(world):
+@pytest.mark.parametrize("world,queues", [(2, 16), (3, 16), (2, 1)])
+def test_striped_aligner_processes_share_one_gpu(world, queues):
     """The real stripe engine (HIP kernels, torch stream and border tensors, event callbacks,
     traceback chain, op gather) in `world` processes on GPU 0; gloo carries the chunks."""
     import os
@@ -112,9 +112,15 @@ def test_striped_aligner_processes_share_one_gpu(world):
     from pathlib import Path
 
     root = Path(__file__).resolve().parent.parent
-    port = 29700 + world + (os.getpid() % 200)
+    port = 29700 + world + 7 * queues + (os.getpid() % 200)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), str(root / "tests" / "helpers" / "run_stripes_gpu_gloo.py")]
-    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=dict(os.environ, OMP_NUM_THREADS="2"))
+    # queues=16: every stream gets a hardware queue of its own (what bench.py sets for N > 1);
+    # queues=1: the transfers are serialised behind the persistent kernel, whose bounded waits must
+    # then expire on every rank and the aligner must fall back to the in-line schedule
+    env = dict(os.environ, OMP_NUM_THREADS="2", GPU_MAX_HW_QUEUES=str(queues), EXPECT_FALLBACK="1" if queues == 1 else "0")
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert p.stdout.count("GPU_STRIPES_OK") == world, p.stdout[-3000:]
+    if queues == 1:
+        assert "falling back" in p.stdout
