@@ -139,7 +139,13 @@ int sa_sw_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const in
  *   SA_EV_RIGHT_READY(k) after the launch that completes rows of chunk k of `right`
  * (chunk k = matrix rows k*chunk_rows+1 .. min(m,(k+1)*chunk_rows), both in ascending k) and the
  * caller enqueues the recv / send of that chunk on the ctx's stream (RCCL send/recv, a peer
- * copy, ...).  NW and LCS; the score is valid on the last stripe.
+ * copy, ...).  NW and LCS: the score is valid on the last stripe.  SW (reference analogue: the
+ * cross-rank arg-max of main.cpp:1151-1177): out->score / end_i / end_j are the stripe's own first
+ * strict row-major maximum (end_j local to the stripe); the caller picks the winner over all stripes
+ * by (score descending, end_i ascending, global column ascending) and starts the traceback there;
+ * the walk ends at the 'X' cell (out->start_j >= 1) or reaches the stripe's left edge
+ * (out->start_j == 0 with start_i >= 1 on a stripe that is not the first: continue on the left
+ * neighbour at its last column, same row).
  * sa_stripe_traceback walks this stripe's codes from (start_i, start_j) (j local to the stripe,
  * 1-based) and stops at the stripe's left edge unless it is the first stripe; out->start_i is
  * the row to continue from on the stripe to the left (at its last column).  The op lists of the

@@ -766,10 +766,12 @@ int orc_nw_banded(const uint8_t* x, int64_t m, const uint8_t* y, int64_t n, int 
 struct orc_stripe {
   int kind, is_first;
   int64_t m, n;
-  uint8_t* T; /* (m+1) x (n+1) direction codes 0/1/2 */
+  uint8_t* T; /* (m+1) x (n+1) direction codes 0/1/2, SW stop cell 3 */
+  int best;   /* SW: first strict row-major maximum inside this stripe (main.cpp:1124-1127) */
+  int64_t best_i, best_j; /* 1-based, j local to the stripe */
 };
 
-/* One column stripe of the NW / LCS matrix, row by row, with the left border taken from `left`
+/* One column stripe of the NW / SW / LCS matrix (kind 0 / 1 / 2), row by row, with the left border taken from `left`
  * (values of the column just left of the stripe) and the stripe's last column written to
  * `right`.  Same recurrences as nw_row / orc_lcs; only the source of column 0 differs. */
 int orc_stripe_fill(int kind, const uint8_t* x, int64_t m, const uint8_t* y, int64_t n, int mode, double go, double ge,
@@ -826,7 +828,7 @@ int orc_stripe_fill(int kind, const uint8_t* x, int64_t m, const uint8_t* y, int
     } else {
       cS[0] = left[2 * i];
       cE[0] = left[2 * i + 1];
-      cF[0] = NEG_INF; /* never read: F of column 0 feeds nothing to the right */
+      cF[0] = (kind == 0) ? NEG_INF : 0; /* never read: F of column 0 feeds nothing to the right */
     }
     for (int64_t j = 1; j <= n; ++j) {
       if (kind == 0) {
@@ -845,6 +847,18 @@ int orc_stripe_fill(int kind, const uint8_t* x, int64_t m, const uint8_t* y, int
         } else {
           cS[j] = cF[j];
           t[j] = 2;
+        }
+      } else if (kind == 1) {
+        /* SW cell, main.cpp:939-1013; diagonal max(S,E,F) == S (Q8), also on the stripe border */
+        sw_cell c = sw_cell_eval(&sc, pS[j - 1], pS[j - 1], pS[j - 1], cS[j - 1], cE[j - 1], pS[j], pF[j], x[i - 1], y[j - 1]);
+        cS[j] = c.s;
+        cE[j] = c.e;
+        cF[j] = c.f;
+        t[j] = c.ptr == 'X' ? 3 : (c.ptr == 'M' ? 0 : ((c.ptr == 'E' || c.ptr == 'e') ? 1 : 2));
+        if (c.s > h->best) {
+          h->best = c.s;
+          h->best_i = i;
+          h->best_j = j;
         }
       } else {
         if (x[i - 1] == y[j - 1]) {
@@ -873,7 +887,7 @@ int orc_stripe_fill(int kind, const uint8_t* x, int64_t m, const uint8_t* y, int
     tt = pF, pF = cF, cF = tt;
     tt = pE, pE = cE, cE = tt;
   }
-  *score = pS[n];
+  *score = (kind == 1) ? h->best : pS[n];
   free(rows);
   *handle = h;
   return sc.bad ? ORC_ERR_INVALID_CODE : ORC_OK;
@@ -885,8 +899,9 @@ int orc_stripe_traceback(orc_stripe* h, int64_t ci, int64_t cj, orc_result* out)
   int64_t cap = 0;
   out->end_i = ci;
   out->end_j = cj;
-  while (h->is_first ? (ci > 0 || cj > 0) : (cj > 0)) {
+  while (h->kind == 1 ? (ci > 0 && cj > 0) : (h->is_first ? (ci > 0 || cj > 0) : (cj > 0))) {
     unsigned c = (ci == 0) ? 1u : (cj == 0 ? 2u : h->T[(size_t)ci * w + cj]);
+    if (c == 3u) break; /* SW stop cell, main.cpp:1233 */
     ops_push(&out->ops, &out->n_ops, &cap, (uint8_t)c);
     if (c == 0)
       --ci, --cj;
@@ -898,6 +913,12 @@ int orc_stripe_traceback(orc_stripe* h, int64_t ci, int64_t cj, orc_result* out)
   out->start_i = ci;
   out->start_j = cj;
   return ORC_OK;
+}
+
+void orc_stripe_best(const orc_stripe* h, int64_t* best, int64_t* bi, int64_t* bj) {
+  *best = h->best;
+  *bi = h->best_i;
+  *bj = h->best_j;
 }
 
 void orc_stripe_free(orc_stripe* h) {

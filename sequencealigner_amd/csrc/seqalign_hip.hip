@@ -656,7 +656,6 @@ int run_stripe_fill(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const 
   if (!ctx) return SA_ERR_ARG;
   if (!out || !d) return fail(ctx, SA_ERR_ARG, "NULL argument");
   memset(out, 0, sizeof *out);
-  if (kind == KIND_SW) return fail(ctx, SA_ERR_UNSUPPORTED, "column stripes are implemented for NW and LCS");
   if (m64 <= 0 || n64 <= 0 || !x || !y) return fail(ctx, SA_ERR_ARG, "a stripe needs m > 0 and n > 0");
   if (m64 > 0x7ff00000LL || d->n_total > 0x7ff00000LL || d->col_begin < 0 || d->col_begin + n64 > d->n_total)
     return fail(ctx, SA_ERR_ARG, "bad stripe geometry");
@@ -689,7 +688,7 @@ int run_stripe_fill(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const 
   if ((sd.stream_in && sd.stream_in == ctx->stream) || (sd.stream_out && sd.stream_out == ctx->stream))
     return fail(ctx, SA_ERR_ARG, "stream_in / stream_out must differ from the ctx stream");
   if ((rc = fill_impl(ctx, kind, x, m, y, n, sc, &sd, 0, out, rowb, colb))) return rc;
-  int h_small[41] = {0};  // [0] score, [40] persistent-kernel error flag
+  int h_small[41] = {0};  // [0] score / SW stripe best, [2..3] SW end cell, [40] persistent-kernel error flag
   HIPCK(ctx, hipMemcpyAsync(h_small, ctx->small.p, sizeof h_small, hipMemcpyDeviceToHost, ctx->stream));
   HIPCK(ctx, hipStreamSynchronize(ctx->stream));
   if (h_small[40] != 0) {
@@ -702,9 +701,15 @@ int run_stripe_fill(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const 
   HIPCK(ctx, hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]));
   out->fill_ms = t01 + t12;
   out->kernel_fill_ms = t12;
-  out->score = h_score;  // meaningful on the last stripe only
+  out->score = h_score;  // NW / LCS: meaningful on the last stripe only; SW: this stripe's best
   out->end_i = m;
   out->end_j = n;
+  if (kind == KIND_SW) {  // first strict row-major maximum inside the stripe, j local (0,0 if the best is 0)
+    unsigned long long pos;
+    memcpy(&pos, &h_small[2], 8);
+    out->end_i = h_score > 0 ? (int64_t)(pos >> 32) : 0;
+    out->end_j = h_score > 0 ? (int64_t)(pos & 0xffffffffu) : 0;
+  }
   return SA_OK;
 }
 

@@ -127,8 +127,8 @@ class StripedAligner:
     def align(self, kind, x, y, mode="dna", gap_open=-5.0, gap_extend=-1.0) -> AlignResult:
         """Every rank passes the same x and y; every rank returns the score, rank 0 also the
         complete op list (identical to the single-GPU sa_nw / sa_lcs result)."""
-        if kind not in ("nw", "lcs"):
-            raise ValueError("column stripes are implemented for nw and lcs")
+        if kind not in ("nw", "lcs", "sw"):
+            raise ValueError(f"unknown kind {kind!r}")
         E, dist, g, G = self.engine, self.dist, self.rank, self.world
         x = np.frombuffer(x.encode("latin-1") if isinstance(x, str) else bytes(x), np.uint8) if not isinstance(x, np.ndarray) else x
         y = np.frombuffer(y.encode("latin-1") if isinstance(y, str) else bytes(y), np.uint8) if not isinstance(y, np.ndarray) else y
@@ -186,6 +186,9 @@ class StripedAligner:
         if int(ok.item()) == 0:
             raise StripeError(f"rank {g}: {failure}" if failure is not None else f"rank {g}: another rank's stripe fill failed")
 
+        if kind == "sw":
+            return self._finish_sw(res, m, n, c0, ng, first)
+
         # traceback, right to left: (exit row) travels g+1 -> g
         if last:
             si = m
@@ -219,6 +222,70 @@ class StripedAligner:
         out.fill_ms, out.kernel_fill_ms, out.traceback_ms = res.fill_ms, res.kernel_fill_ms, tb.traceback_ms
         out.n_launches, out.rows_per_lane, out.tile_steps = res.n_launches, res.rows_per_lane, res.tile_steps
         out.extra = {"stripe": (c0, c1), "stripe_ops": len(tb.ops)}
+        return out
+
+    def _gather_ops(self, my_ops):
+        """op lists to rank 0, right-most stripe first"""
+        E, dist, g, G = self.engine, self.dist, self.rank, self.world
+        if g == 0:
+            parts = {0: my_ops}
+            for src in range(1, G):
+                ln = E.small([0])
+                dist.recv(ln, src=src)
+                buf = E.empty_bytes(int(ln.item()))
+                if int(ln.item()):
+                    dist.recv(buf, src=src)
+                parts[src] = buf.cpu().numpy()
+            return np.concatenate([parts[k] for k in range(G - 1, -1, -1)])
+        dist.send(E.small([len(my_ops)]), dst=0)
+        if len(my_ops):
+            dist.send(E.bytes_tensor(my_ops), dst=0)
+        return np.zeros(0, np.uint8)
+
+    def _finish_sw(self, res, m, n, c0, ng, first) -> AlignResult:
+        """SW over stripes: the reference's cross-rank arg-max (main.cpp:1151-1177) with its
+        first-strict-row-major-maximum rule, then the traceback from the winning cell leftwards
+        until the 'X' cell (main.cpp:1233)."""
+        E, dist, g, G = self.engine, self.dist, self.rank, self.world
+        INF = (1 << 62)
+        best = E.small([int(res.score)])
+        dist.all_reduce(best, op=dist.ReduceOp.MAX)
+        score = int(best.item())
+        if score <= 0:  # no positive cell anywhere: empty local alignment
+            return AlignResult(0, (0, 0), (0, 0), np.zeros(0, np.uint8))
+        # among the cells attaining it: smallest row, then smallest (global) column
+        key = E.small([(int(res.end[0]) << 32) | (c0 + int(res.end[1])) if int(res.score) == score else INF])
+        dist.all_reduce(key, op=dist.ReduceOp.MIN)
+        bi, bj = int(key.item()) >> 32, int(key.item()) & 0xFFFFFFFF
+        bounds = [n * k // G for k in range(G + 1)]
+        owner = next(k for k in range(G) if bounds[k] < bj <= bounds[k + 1])
+        ops = np.zeros(0, np.uint8)
+        stop = [0, 0]  # the 'X' cell in global coordinates, contributed by the rank where the walk ended
+        tb_ms = 0.0
+        if g <= owner:
+            if g == owner:
+                row, col, done = bi, bj - c0, 0
+            else:
+                t = E.small([0, 0])
+                dist.recv(t, src=g + 1)
+                row, done = (int(v) for v in t.tolist())
+                col = ng
+            if not done:
+                tb = E.stripe_traceback(row, col)
+                ops, tb_ms = tb.ops, tb.traceback_ms
+                goes_on = (not first) and tb.start[1] == 0 and tb.start[0] > 0
+                if not goes_on:
+                    stop = [int(tb.start[0]), c0 + int(tb.start[1])]
+                row, done = int(tb.start[0]), 0 if goes_on else 1
+            if not first:
+                dist.send(E.small([row, done]), dst=g - 1)
+        st = E.small(stop)
+        dist.all_reduce(st, op=dist.ReduceOp.SUM)
+        all_ops = self._gather_ops(ops)
+        out = AlignResult(score, (bi, bj), tuple(int(v) for v in st.tolist()), all_ops)
+        out.fill_ms, out.kernel_fill_ms, out.traceback_ms = res.fill_ms, res.kernel_fill_ms, tb_ms
+        out.n_launches, out.rows_per_lane, out.tile_steps = res.n_launches, res.rows_per_lane, res.tile_steps
+        out.extra = {"stripe": (c0, c0 + ng), "stripe_ops": len(ops), "owner": owner}
         return out
 
     def _on_rank0(self, kind, x, y, mode, go, ge) -> AlignResult:

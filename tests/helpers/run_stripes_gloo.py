@@ -30,13 +30,21 @@ def main():
         cases.append((x, y))
     cases.append((np.frombuffer(b"A" * 300, np.uint8), np.frombuffer(b"A" * 257, np.uint8)))
     cases.append((np.frombuffer(b"ACGT" * 100, np.uint8), np.frombuffer(b"TTTT" * 50 + b"ACGT" * 60, np.uint8)))
+    rng = np.random.default_rng(7)
+    noise = lambda k: rng.choice(np.frombuffer(b"ACGT", np.uint8), k)  # noqa: E731
+    core = noise(400)
+    cases.append((np.concatenate([noise(150), core, noise(90)]), np.concatenate([noise(300), core, noise(500)])))  # spans stripes
+    cases.append((np.concatenate([noise(50), core[:60], noise(50)]), np.concatenate([noise(700), core[:60], noise(40)])))  # inside the last
+    cases.append((np.frombuffer(b"A" * 200, np.uint8), np.frombuffer(b"C" * 300, np.uint8)))  # score 0
     ok = True
     for x, y in cases:
-        for kind in ("nw", "lcs"):
+        for kind in ("nw", "lcs", "sw"):
             for go, ge in ((-5.0, -1.0), (-2.0, -2.0)):
                 r = al.align(kind, x, y, "dna", go, ge)
-                want = orc.lcs(x, y) if kind == "lcs" else orc.nw(x, y, "dna", go, ge)
+                want = orc.lcs(x, y) if kind == "lcs" else getattr(orc, kind)(x, y, "dna", go, ge)
                 good = r.score == want.score and (rank != 0 or np.array_equal(r.ops, want.ops))
+                if kind == "sw":  # every rank learns the end cell and the 'X' cell
+                    good = good and tuple(r.end) == tuple(want.end) and tuple(r.start) == tuple(want.start)
                 if not good:
                     print(f"rank {rank}: MISMATCH {kind} m={len(x)} n={len(y)} go={go}: {r.score} vs {want.score}", flush=True)
                 ok = ok and good

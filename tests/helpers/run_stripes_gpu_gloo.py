@@ -80,7 +80,7 @@ def main():
     cases = [(3000, 1, True)] if expect_fallback else [(3000, 1, True), (20000, 2, True), (5000, 3, False), (100, 4, True)]
     for n, seed, rel in cases:
         x, y = dna_pair(n, seed=seed, related=rel)
-        for kind in ("nw", "lcs"):
+        for kind in ("nw", "lcs", "sw"):
             try:
                 r = al.align(kind, x, y, "dna")
             except StripeError as e:
@@ -88,8 +88,13 @@ def main():
                 fell_back = True
                 al.overlap = False
                 r = al.align(kind, x, y, "dna")
-            want = orc.lcs(x, y, packed=True) if kind == "lcs" else orc.nw(x, y, "dna", packed=True)
+            if kind == "sw":
+                want = orc.sw(x, y, "dna")
+            else:
+                want = orc.lcs(x, y, packed=True) if kind == "lcs" else orc.nw(x, y, "dna", packed=True)
             good = r.score == want.score and (rank != 0 or np.array_equal(r.ops, want.ops))
+            if kind == "sw":
+                good = good and tuple(r.end) == tuple(want.end) and tuple(r.start) == tuple(want.start)
             # striped runs take the overlapped schedule: one persistent launch per stripe
             if n >= 64 * world and r.n_launches != 1 and not fell_back:
                 print(f"rank {rank}: {kind} n={n} ran {r.n_launches} launches, expected the persistent pipeline", flush=True)

@@ -92,6 +92,69 @@ def test_stripes_equal_single_gpu(engine, oracle, kind):
     engine.set_tuning(0, 0)
 
 
+def striped_sw(engine, x, y, G, mode, go, ge, chunk_rows):
+    """SW over G stripes replayed on one GPU: per-stripe best -> winner by (score desc, row asc,
+    column asc) -> traceback from the winner leftwards until the 'X' cell."""
+    import sequencealigner_amd as sa
+
+    xb = np.frombuffer(x.encode(), np.uint8)
+    yb = np.frombuffer(y.encode(), np.uint8)
+    m, n = len(xb), len(yb)
+    bounds = [n * k // G for k in range(G + 1)]
+    borders = [None] + [DevBuf((m + 1) * 8) for _ in range(G - 1)] + [None]
+    engs = [engine] + [sa.Engine(0) for _ in range(G - 1)]
+    cands = []
+    for g in range(G):
+        left, right = borders[g], borders[g + 1]
+        r = engs[g].stripe_fill("sw", xb, yb[bounds[g]:bounds[g + 1]], n, bounds[g], g == 0, g == G - 1,
+                                None if left is None else left.data_ptr(), None if right is None else right.data_ptr(),
+                                chunk_rows, lambda ev, k: None, mode, go, ge)
+        cands.append((-r.score, r.end[0], bounds[g] + r.end[1], g))
+    neg, bi, bj, owner = min(cands)
+    score, ops, start = -neg, [], (0, 0)
+    if score > 0:
+        row, col = bi, bj - bounds[owner]
+        for g in range(owner, -1, -1):
+            tb = engs[g].stripe_traceback(row, col)
+            ops.append(tb.ops)
+            start = (tb.start[0], bounds[g] + tb.start[1])
+            if not (g > 0 and tb.start[1] == 0 and tb.start[0] > 0):
+                break
+            row, col = tb.start[0], bounds[g] - bounds[g - 1]
+    else:
+        bi = bj = 0
+    for e in engs[1:]:
+        e.close()
+    for b in borders:
+        if b is not None:
+            b.free()
+    return score, (bi, bj), start, (np.concatenate(ops) if ops else np.zeros(0, np.uint8))
+
+
+def test_sw_stripes_equal_oracle(engine, oracle):
+    rng = np.random.default_rng(47)
+    core = rand_seq(rng, 900, DNA)
+    cases = []
+    for (m, G, K, C, R) in [(700, 2, 1, 64, 128), (3000, 3, 2, 128, 512), (5000, 4, 4, 64, 1024), (2500, 8, 8, 256, 512)]:
+        x = rand_seq(rng, m, DNA)
+        cases.append((x, mutate(rng, x, DNA), G, K, C, R))
+    # a local hit that spans stripe boundaries inside unrelated flanks; one inside a single stripe; none
+    cases.append((rand_seq(rng, 400, DNA) + core + rand_seq(rng, 300, DNA), rand_seq(rng, 1500, DNA) + mutate(rng, core, DNA) + rand_seq(rng, 1200, DNA), 4, 2, 64, 512))
+    cases.append((rand_seq(rng, 300, DNA) + core[:80] + rand_seq(rng, 100, DNA), rand_seq(rng, 2500, DNA) + core[:80] + rand_seq(rng, 60, DNA), 3, 1, 64, 128))
+    cases.append(("A" * 600, "C" * 900, 3, 2, 64, 128))
+    for persistent in (1, 0):
+        engine.set_option("persistent", persistent)
+        for (x, y, G, K, C, R) in cases:
+            engine.set_tuning(K, C)
+            want = oracle.sw(x, y, "dna")
+            score, end, start, ops = striped_sw(engine, x, y, G, "dna", -5.0, -1.0, R)
+            assert score == want.score, (len(x), G, persistent)
+            assert tuple(end) == tuple(want.end) and tuple(start) == tuple(want.start), (len(x), G, end, want.end, start, want.start)
+            assert np.array_equal(ops, want.ops), (len(x), G, persistent)
+    engine.set_tuning(0, 0)
+    engine.set_option("persistent", 1)
+
+
 def test_stripes_protein_and_gaps(engine, oracle):
     rng = np.random.default_rng(43)
     x = rand_seq(rng, 1800, PROT20)
