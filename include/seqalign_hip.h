@@ -95,7 +95,8 @@ int sa_release_workspace(sa_ctx* ctx);
 /* tuning overrides, 0 = automatic: rows per lane K in {1,2,4,8}, tile steps C multiple of 64 */
 int sa_set_tuning(sa_ctx* ctx, int rows_per_lane, int tile_steps);
 /* engine options: "persistent" 0/1 (fill as one persistent strip-pipelined launch instead of one
- * launch per tile diagonal; same results), "waves_per_simd" 1..4 (grid of the persistent launch) */
+ * launch per tile diagonal; same results), "waves_per_simd" 1..4 (grid of the persistent launch),
+ * "batch_trace_budget_mb" (sa_sw_batch_align: device bytes of direction codes per chunk) */
 int sa_set_option(sa_ctx* ctx, const char* name, int64_t value);
 
 /* The reference's two built-in scoring schemes with default penalties -5/-1
@@ -126,6 +127,22 @@ int sa_sw_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const in
                 const int64_t* off_y, const int32_t* len_y, int64_t n_pairs,
                 const sa_scoring* sc, int32_t* score, int32_t* end_i, int32_t* end_j,
                 float* kernel_ms);
+
+/* Many independent pairs with their full local alignments: per pair what sa_sw returns (score, end
+ * cell, the 'X' cell where the traceback stopped, the op list end -> start).  The reference has no
+ * batch mode -- it aligns one pair per process (processFasta reads one record, main.cpp:290-308) --
+ * so this is localalign()'s fill + traceback (main.cpp:1099-1128, 1182-1265) applied to every pair
+ * (SURVEY.md 8f-1).  The ops of pair k are ops_pool[ops_off[k] .. ops_off[k] + n_ops[k]); ops_off[k]
+ * is the sum over earlier pairs of (len_x + len_y) rounded up to 4.  *ops_pool is library-owned host
+ * memory, released with sa_free_pool().  Device memory for the direction codes is bounded by
+ * processing the pairs in chunks (sa_set_option "batch_trace_budget_mb", default 32768).
+ * Invalid residues: as sa_sw_batch (score INT32_MIN, no ops, SA_ERR_INVALID_CODE after the rest). */
+int sa_sw_batch_align(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x,
+                      const int64_t* off_y, const int32_t* len_y, int64_t n_pairs, const sa_scoring* sc,
+                      int32_t* score, int32_t* end_i, int32_t* end_j, int32_t* start_i, int32_t* start_j,
+                      int64_t* ops_off, int32_t* n_ops, uint8_t** ops_pool, int64_t* ops_pool_bytes,
+                      float* kernel_ms);
+void sa_free_pool(uint8_t* pool);
 
 /* ---- one long pair over several GPUs: column stripes ----
  *

@@ -1,5 +1,7 @@
-// sa_batch.h -- inter-task Smith-Waterman for many independent pairs (score + end cell only):
-// the first fill pass of the reference's localalign() (main.cpp:1099-1128) per pair.
+// sa_batch.h -- inter-task Smith-Waterman for many independent pairs: the first fill pass of the
+// reference's localalign() (main.cpp:1099-1128) per pair (score + end cell), and -- TRACE
+// instances -- the same sweep with 2-bit direction codes stored per cell so that a second kernel
+// can walk every pair's local alignment back to its 'X' cell (main.cpp:1182-1265 per pair).
 //
 // One wavefront per pair.  The pair's query (rows) is spread over the 64 lanes, K = ceil(m/64)
 // rows per lane (K is a template parameter, 1..16, pairs are grouped by K on the host), and the
@@ -27,6 +29,8 @@ struct PairDesc {
   int m, n;
   int idx;   // position in the caller's arrays
   int pad;
+  long long off_trace;  // TRACE: first dword of the pair's codes in BatchArgs::trace
+  long long off_ops;    // TRACE: first byte of the pair's op slot (capacity m + n, 4-byte aligned)
 };
 
 struct BatchArgs {
@@ -42,6 +46,12 @@ struct BatchArgs {
   int* end_i;
   int* end_j;
   int* err;               // set to 1 if any pair had an invalid residue
+  // alignments (TRACE kernels + sw_batch_traceback)
+  uint32_t* trace;        // per pair [ceil((n+63)/16)][64 lanes][K] dwords, 16 skewed steps of 2-bit codes each
+  uint8_t* ops;           // per pair a slot of m + n bytes
+  int* n_ops;
+  int* start_i;
+  int* start_j;
 };
 
 constexpr int kBatchMaxN = 4095;  // LDS room for the encoded target; the host admits n <= kBatchMaxN - 200
@@ -53,7 +63,11 @@ struct BatchGeo {
   static constexpr int ROWB = 64 * PW * 4;
 };
 
-template <int K>
+// TRACE: values are held as 4*score with the candidate's identity in the two low bits (M 2, E 1,
+// F 0, zero cell 3), exactly as in the single-pair kernels (sa_kernels.h), so the direction code
+// is the low two bits of the cell's maximum; the PAD score becomes -32 (4*(-32)+2 fits the int8
+// profile; any negative PAD keeps the two properties above).
+template <int K, bool TRACE>
 __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
   using G = BatchGeo<K>;
   extern __shared__ uint32_t lds[];
@@ -103,7 +117,8 @@ __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
     for (int i = 0; i < G::PW; ++i) w[i] = 0;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      int v = (sym == alpha) ? -128 : (xi[k] < 0 ? 0 : (int)subt[xi[k] * alpha + sym]);
+      int v = (sym == alpha) ? (TRACE ? -32 : -128) : (xi[k] < 0 ? 0 : (int)subt[xi[k] * alpha + sym]);
+      if (TRACE) v = 4 * v + 2;  // tagged M candidate; the host guarantees |sigma| <= 31
       w[k / 4] |= (uint32_t)(uint8_t)(int8_t)v << (8 * (k & 3));
     }
 #pragma unroll
@@ -112,15 +127,16 @@ __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
   __syncthreads();
 
   const char* ldsLane = reinterpret_cast<const char*>(prof) + lane * 4 * G::PW;
-  const int go = a.go, ge = a.ge, CB = a.CB;
+  const int go = TRACE ? 4 * a.go : a.go, ge = TRACE ? 4 * a.ge : a.ge, CB = a.CB;
   int H[K], E[K];
   uint32_t bk[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     H[k] = 0;
-    E[k] = 0;
+    E[k] = TRACE ? 1 : 0;
     bk[k] = 0;
   }
+  uint32_t* tdst = TRACE ? a.trace + pd.off_trace + (size_t)lane * K : nullptr;
   int passH = 0, passF = 0, dprev = 0;
   int ypass = alpha * G::ROWB;
   const int cbase = (1 << CB) - 64;  // key low bits = cbase - column >= 0 for every column the sweep touches
@@ -153,6 +169,11 @@ __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
 
 #pragma unroll 1
   for (int t0 = 0; t0 < nsteps; t0 += 16) {
+    uint32_t tacc[TRACE ? K : 1];
+    if (TRACE) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) tacc[k] = 0;
+    }
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
       const int t = t0 + u;
@@ -173,10 +194,21 @@ __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
       for (int k = 0; k < K; ++k) {
         const int sg = (int)(int8_t)(pw[k / 4] >> (8 * (k & 3)));
         const int left = H[k];
-        const int f = max(max(up + go, uf + ge), 0);
-        const int e = max(max(left + go, E[k] + ge), 0);
-        const int h = max(max(diag + sg, e), f);
-        bk[k] = max(bk[k], ((uint32_t)h << CB) + (uint32_t)cinv);
+        int f, e, h;
+        if (TRACE) {
+          f = max(max(up + go, uf + ge), 0);            // tag 0
+          e = max(max(left + go + 1, E[k] + ge), 1);    // tag 1
+          const int mv = max(diag + sg, 2);             // tag 2
+          const int ht = max(max(max(mv, e), f), 3);    // a zero cell wins with tag 3 = 'X'
+          tacc[k] = __builtin_amdgcn_alignbit((uint32_t)ht, tacc[k], 2);
+          h = ht & ~3;
+          bk[k] = max(bk[k], ((uint32_t)h << (CB - 2)) + (uint32_t)cinv);
+        } else {
+          f = max(max(up + go, uf + ge), 0);
+          e = max(max(left + go, E[k] + ge), 0);
+          h = max(max(diag + sg, e), f);
+          bk[k] = max(bk[k], ((uint32_t)h << CB) + (uint32_t)cinv);
+        }
         E[k] = e;
         diag = left;
         H[k] = h;
@@ -189,6 +221,11 @@ __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
       yv = yv_next;
 #pragma unroll
       for (int i = 0; i < G::PW; ++i) pw[i] = pw_next[i];
+    }
+    if (TRACE) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) tdst[k] = tacc[k];
+      tdst += 64 * K;
     }
   }
 
@@ -229,6 +266,52 @@ __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
       a.end_j[pd.idx] = (int)(0xffffu - (key & 0xffffu)) + 1;
     }
   }
+}
+
+// dwords of codes one pair occupies
+inline long long batch_trace_dwords(int m, int n) {
+  const int K = (m + 63) / 64;
+  const long long nsteps = ((n + 63 + 15) / 16) * 16;
+  return nsteps / 16 * 64 * K;
+}
+
+// One thread per pair follows the pointers from the pair's end cell to its 'X' cell
+// (main.cpp:1226-1262) and writes the moves, end -> start, four to a dword.
+__global__ void sw_batch_traceback(const BatchArgs a) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.n_desc) return;
+  const PairDesc pd = a.desc[q];
+  const int K = (pd.m + 63) / 64;
+  int i = a.end_i[pd.idx], j = a.end_j[pd.idx];
+  const int sc = a.score[pd.idx];
+  const uint32_t* tr = a.trace + pd.off_trace;
+  uint32_t* out = reinterpret_cast<uint32_t*>(a.ops + pd.off_ops);
+  int nops = 0;
+  uint32_t acc = 0;
+  if (sc > 0) {
+    while (i > 0 && j > 0) {
+      const int r = i - 1, c = j - 1;
+      const int l = r / K, k = r - l * K;
+      const int t = c + l;
+      const uint32_t raw = (tr[((size_t)(t >> 4) * 64 + l) * K + k] >> (2 * (t & 15))) & 3u;
+      if (raw == 3u) break;  // 'X'
+      const uint32_t op = 2u - raw;
+      acc |= op << (8 * (nops & 3));
+      if ((nops & 3) == 3) {
+        out[nops >> 2] = acc;
+        acc = 0;
+      }
+      ++nops;
+      if (op != 1u) --i;
+      if (op != 2u) --j;
+    }
+    if (nops & 3) out[nops >> 2] = acc;
+  } else {
+    i = j = 0;
+  }
+  a.n_ops[pd.idx] = nops;
+  a.start_i[pd.idx] = sc > 0 ? i : 0;
+  a.start_j[pd.idx] = sc > 0 ? j : 0;
 }
 
 template <int K>

@@ -38,6 +38,7 @@ struct sa_ctx {
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [4]: stripe flags reset
   std::string err;
   int force_K = 0, force_C = 0;
+  size_t batch_trace_budget = (size_t)32 << 30;  // sa_sw_batch_align: device bytes of direction codes per chunk
   int persist = 1;  // 1: persistent strip pipeline (one launch) where it applies
   int wps = 1;      // persistent kernel: waves per SIMD to launch
   int n_cu = 256;
@@ -730,38 +731,58 @@ int run_stripe_traceback(sa_ctx* ctx, int64_t start_i, int64_t start_j, sa_resul
 }
 
 template <int K>
-void launch_batch(hipStream_t st, int count, int alpha, const BatchArgs& a) {
-  hipLaunchKernelGGL(sw_batch_kernel<K>, dim3(count), dim3(64), batch_lds_bytes<K>(alpha), st, a);
+void launch_batch(hipStream_t st, int count, int alpha, const BatchArgs& a, bool trace) {
+  if (trace)
+    hipLaunchKernelGGL((sw_batch_kernel<K, true>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha), st, a);
+  else
+    hipLaunchKernelGGL((sw_batch_kernel<K, false>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha), st, a);
 }
 
-void launch_batch_k(int K, hipStream_t st, int count, int alpha, const BatchArgs& a) {
+void launch_batch_k(int K, hipStream_t st, int count, int alpha, const BatchArgs& a, bool trace = false) {
   switch (K) {
-    case 1: launch_batch<1>(st, count, alpha, a); break;
-    case 2: launch_batch<2>(st, count, alpha, a); break;
-    case 3: launch_batch<3>(st, count, alpha, a); break;
-    case 4: launch_batch<4>(st, count, alpha, a); break;
-    case 5: launch_batch<5>(st, count, alpha, a); break;
-    case 6: launch_batch<6>(st, count, alpha, a); break;
-    case 7: launch_batch<7>(st, count, alpha, a); break;
-    case 8: launch_batch<8>(st, count, alpha, a); break;
-    case 9: launch_batch<9>(st, count, alpha, a); break;
-    case 10: launch_batch<10>(st, count, alpha, a); break;
-    case 11: launch_batch<11>(st, count, alpha, a); break;
-    case 12: launch_batch<12>(st, count, alpha, a); break;
-    case 13: launch_batch<13>(st, count, alpha, a); break;
-    case 14: launch_batch<14>(st, count, alpha, a); break;
-    case 15: launch_batch<15>(st, count, alpha, a); break;
-    default: launch_batch<16>(st, count, alpha, a); break;
+    case 1: launch_batch<1>(st, count, alpha, a, trace); break;
+    case 2: launch_batch<2>(st, count, alpha, a, trace); break;
+    case 3: launch_batch<3>(st, count, alpha, a, trace); break;
+    case 4: launch_batch<4>(st, count, alpha, a, trace); break;
+    case 5: launch_batch<5>(st, count, alpha, a, trace); break;
+    case 6: launch_batch<6>(st, count, alpha, a, trace); break;
+    case 7: launch_batch<7>(st, count, alpha, a, trace); break;
+    case 8: launch_batch<8>(st, count, alpha, a, trace); break;
+    case 9: launch_batch<9>(st, count, alpha, a, trace); break;
+    case 10: launch_batch<10>(st, count, alpha, a, trace); break;
+    case 11: launch_batch<11>(st, count, alpha, a, trace); break;
+    case 12: launch_batch<12>(st, count, alpha, a, trace); break;
+    case 13: launch_batch<13>(st, count, alpha, a, trace); break;
+    case 14: launch_batch<14>(st, count, alpha, a, trace); break;
+    case 15: launch_batch<15>(st, count, alpha, a, trace); break;
+    default: launch_batch<16>(st, count, alpha, a, trace); break;
   }
 }
 
+// Outputs of the aligning variant (sa_sw_batch_align): per pair the 'X' cell and the op list.
+struct BatchAlign {
+  int32_t* start_i;
+  int32_t* start_j;
+  int64_t* ops_off;   // byte offset of the pair's ops in the pool: sum over earlier pairs of (m + n) rounded up to 4
+  int32_t* n_ops;
+  uint8_t** pool;
+  int64_t* pool_bytes;
+};
+
 // Many independent pairs: one wavefront per pair (sa_batch.h).  Pairs the fast kernel does not
-// admit (query > 1024 rows, very long target) go through the single-pair SW kernels, score only.
+// admit (query > 1024 rows, very long target) go through the single-pair SW kernels.
+// al == nullptr: score + end cell only.  Otherwise the fill also stores direction codes (in chunks
+// that bound the device memory taken by them) and a second kernel walks every pair back.
 int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x, const int64_t* off_y,
               const int32_t* len_y, int64_t n_pairs, const sa_scoring* sc, int32_t* score, int32_t* end_i, int32_t* end_j,
-              float* kernel_ms) {
+              float* kernel_ms, const BatchAlign* al = nullptr) {
   if (!ctx) return SA_ERR_ARG;
   if (kernel_ms) *kernel_ms = 0.f;
+  if (al) {
+    if (!al->start_i || !al->start_j || !al->ops_off || !al->n_ops || !al->pool) return fail(ctx, SA_ERR_ARG, "bad batch arguments");
+    *al->pool = nullptr;
+    if (al->pool_bytes) *al->pool_bytes = 0;
+  }
   if (n_pairs < 0 || (n_pairs > 0 && (!seqs || !off_x || !len_x || !off_y || !len_y || !score || !end_i || !end_j)))
     return fail(ctx, SA_ERR_ARG, "bad batch arguments");
   if (!sc || !sc->sub || !sc->idx256 || sc->alpha < 1 || sc->alpha > 31) return fail(ctx, SA_ERR_ARG, "bad scoring");
@@ -774,6 +795,32 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
   HIPCK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int alpha = sc->alpha;
+  int64_t pool_total = 0;
+  if (al) {
+    int smax = 0;
+    for (int i = 0; i < alpha * alpha; ++i) smax = std::max(smax, std::abs((int)sc->sub[i]));
+    if (smax > 31) return fail(ctx, SA_ERR_UNSUPPORTED, "substitution scores beyond +-31 do not fit the int8 tagged profile");
+    for (int64_t k = 0; k < n_pairs; ++k) {
+      if (len_x[k] < 0 || len_y[k] < 0) return fail(ctx, SA_ERR_ARG, "negative length in pair %lld", (long long)k);
+      al->ops_off[k] = pool_total;
+      al->n_ops[k] = 0;
+      al->start_i[k] = al->start_j[k] = 0;
+      pool_total += ((int64_t)len_x[k] + len_y[k] + 3) & ~3LL;
+    }
+    *al->pool = (uint8_t*)malloc((size_t)std::max<int64_t>(pool_total, 4));
+    if (!*al->pool) return fail(ctx, SA_ERR_NOMEM, "host malloc of the %lld-byte op pool failed", (long long)pool_total);
+    if (al->pool_bytes) *al->pool_bytes = pool_total;
+  }
+  struct PoolGuard {  // the pool goes back to the caller only with SA_OK / SA_ERR_INVALID_CODE
+    const BatchAlign* al;
+    bool keep = false;
+    ~PoolGuard() {
+      if (al && !keep && *al->pool) {
+        free(*al->pool);
+        *al->pool = nullptr;
+      }
+    }
+  } guard{al};
 
   // group by rows-per-lane K = ceil(m/64); counting sort keeps the caller's order inside a group
   std::vector<PairDesc> desc;
@@ -808,7 +855,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     for (int64_t k = 0; k < n_pairs; ++k) {
       if (len_x[k] == 0 || len_y[k] == 0 || len_x[k] > kBatchMaxM || len_y[k] > kBatchMaxN - 200) continue;
       const int K = (len_x[k] + 63) / 64;
-      desc[(size_t)cur[K]++] = PairDesc{off_x[k], off_y[k], len_x[k], len_y[k], (int)k, 0};
+      desc[(size_t)cur[K]++] = PairDesc{off_x[k], off_y[k], len_x[k], len_y[k], (int)k, 0, 0, 0};
     }
   }
 
@@ -817,13 +864,44 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
   if (!desc.empty()) {
     if ((rc = ensure(ctx, ctx->b_seq, (size_t)pool_end + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_desc, desc.size() * sizeof(PairDesc)))) return rc;
-    if ((rc = ensure(ctx, ctx->b_out, (size_t)n_pairs * 12 + 1024 + 2048))) return rc;
+    if ((rc = ensure(ctx, ctx->b_out, (size_t)n_pairs * 24 + 1024 + 2048))) return rc;
+    // aligning variant: cut the (K-sorted) pair list into chunks whose codes fit the trace budget;
+    // offsets of codes and op slots are relative to the chunk's buffers
+    struct Chunk {
+      size_t lo, hi;
+      long long trace_dwords, ops_bytes;
+    };
+    std::vector<Chunk> chunks;
+    if (al) {
+      const long long budget = (long long)ctx->batch_trace_budget / 4;
+      Chunk c{0, 0, 0, 0};
+      for (size_t q = 0; q < desc.size(); ++q) {
+        const long long td = batch_trace_dwords(desc[q].m, desc[q].n);
+        if (c.hi > c.lo && c.trace_dwords + td > budget) {
+          chunks.push_back(c);
+          c = Chunk{q, q, 0, 0};
+        }
+        desc[q].off_trace = c.trace_dwords;
+        desc[q].off_ops = c.ops_bytes;
+        c.trace_dwords += td;
+        c.ops_bytes += ((long long)desc[q].m + desc[q].n + 3) & ~3LL;
+        c.hi = q + 1;
+      }
+      chunks.push_back(c);
+      long long tmax = 0, omax = 0;
+      for (const Chunk& ch : chunks) tmax = std::max(tmax, ch.trace_dwords), omax = std::max(omax, ch.ops_bytes);
+      if ((rc = ensure(ctx, ctx->trace, (size_t)tmax * 4))) return rc;
+      if ((rc = ensure(ctx, ctx->ops, (size_t)omax + 64))) return rc;
+    }
     HIPCK(ctx, hipMemcpyAsync(ctx->b_seq.p, seqs, (size_t)pool_end, hipMemcpyHostToDevice, st));
     HIPCK(ctx, hipMemcpyAsync(ctx->b_desc.p, desc.data(), desc.size() * sizeof(PairDesc), hipMemcpyHostToDevice, st));
     int* d_score = (int*)ctx->b_out.p;
     int* d_ei = d_score + n_pairs;
     int* d_ej = d_ei + n_pairs;
-    int* d_err = d_ej + n_pairs;
+    int* d_nops = d_ej + n_pairs;
+    int* d_si = d_nops + n_pairs;
+    int* d_sj = d_si + n_pairs;
+    int* d_err = d_sj + n_pairs;
     int8_t* d_sub = (int8_t*)(d_err + 16);
     uint8_t* d_map = (uint8_t*)(d_sub + 1024);
     HIPCK(ctx, hipMemsetAsync(d_err, 0, 64, st));
@@ -840,39 +918,82 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     a.end_i = d_ei;
     a.end_j = d_ej;
     a.err = d_err;
-    HIPCK(ctx, hipEventRecord(ctx->ev[0], st));
-    for (int K = 16; K >= 1; --K) {
-      if (!group_count[K]) continue;
-      a.desc = (const PairDesc*)ctx->b_desc.p + group_start[K];
-      a.n_desc = group_count[K];
-      int CB = 8;
-      while ((1 << CB) < group_nmax[K] + 160) ++CB;
-      a.CB = CB;
-      launch_batch_k(K, st, group_count[K], alpha, a);
+    a.trace = (uint32_t*)ctx->trace.p;
+    a.ops = (uint8_t*)ctx->ops.p;
+    a.n_ops = d_nops;
+    a.start_i = d_si;
+    a.start_j = d_sj;
+    if (!al) chunks.push_back({0, desc.size(), 0, 0});
+    std::vector<uint8_t> stage;
+    std::vector<int> h_nops;
+    float ms_total = 0;
+    for (const auto& ch : chunks) {
+      HIPCK(ctx, hipEventRecord(ctx->ev[0], st));
+      for (int K = 16; K >= 1; --K) {  // the part of group K inside this chunk
+        const size_t glo = std::max<size_t>(ch.lo, (size_t)group_start[K]);
+        const size_t ghi = std::min<size_t>(ch.hi, (size_t)group_start[K] + group_count[K]);
+        if (glo >= ghi) continue;
+        a.desc = (const PairDesc*)ctx->b_desc.p + glo;
+        a.n_desc = (int)(ghi - glo);
+        int CB = 8;
+        while ((1 << CB) < group_nmax[K] + 160) ++CB;
+        a.CB = CB;
+        launch_batch_k(K, st, a.n_desc, alpha, a, al != nullptr);
+      }
+      if (al) {
+        a.desc = (const PairDesc*)ctx->b_desc.p + ch.lo;
+        a.n_desc = (int)(ch.hi - ch.lo);
+        hipLaunchKernelGGL(sw_batch_traceback, dim3((a.n_desc + 63) / 64), dim3(64), 0, st, a);
+      }
+      HIPCK(ctx, hipGetLastError());
+      HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
+      if (al) {  // the chunk's op slots come back in one copy and are scattered into the caller-ordered pool
+        stage.resize((size_t)ch.ops_bytes + 64);
+        h_nops.resize((size_t)n_pairs);
+        HIPCK(ctx, hipMemcpyAsync(stage.data(), ctx->ops.p, (size_t)ch.ops_bytes, hipMemcpyDeviceToHost, st));
+        HIPCK(ctx, hipMemcpyAsync(h_nops.data(), d_nops, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+      }
+      HIPCK(ctx, hipStreamSynchronize(st));
+      float ms = 0;
+      HIPCK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+      ms_total += ms;
+      if (al)
+        for (size_t q = ch.lo; q < ch.hi; ++q) {
+          const PairDesc& d = desc[q];
+          memcpy(*al->pool + al->ops_off[d.idx], stage.data() + d.off_ops, (size_t)h_nops[(size_t)d.idx]);
+        }
     }
-    HIPCK(ctx, hipGetLastError());
-    HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
     // results come back for every index; slots of pairs handled elsewhere are overwritten below
-    std::vector<int> h_out((size_t)n_pairs * 3);
-    HIPCK(ctx, hipMemcpyAsync(h_out.data(), d_score, (size_t)n_pairs * 12, hipMemcpyDeviceToHost, st));
+    std::vector<int> h_out((size_t)n_pairs * 6);
+    HIPCK(ctx, hipMemcpyAsync(h_out.data(), d_score, (size_t)n_pairs * (al ? 24 : 12), hipMemcpyDeviceToHost, st));
     HIPCK(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
     HIPCK(ctx, hipStreamSynchronize(st));
-    float ms = 0;
-    HIPCK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
-    if (kernel_ms) *kernel_ms = ms;
+    if (kernel_ms) *kernel_ms = ms_total;
     for (const PairDesc& d : desc) {
       score[d.idx] = h_out[(size_t)d.idx];
       end_i[d.idx] = h_out[(size_t)n_pairs + d.idx];
       end_j[d.idx] = h_out[(size_t)2 * n_pairs + d.idx];
+      if (al) {
+        const bool bad = score[d.idx] == INT32_MIN;
+        al->n_ops[d.idx] = bad ? 0 : h_out[(size_t)3 * n_pairs + d.idx];
+        al->start_i[d.idx] = bad ? 0 : h_out[(size_t)4 * n_pairs + d.idx];
+        al->start_j[d.idx] = bad ? 0 : h_out[(size_t)5 * n_pairs + d.idx];
+      }
     }
   }
   for (int64_t k : slow) {
     sa_result r;
-    const int rc1 = run_pair(ctx, KIND_SW, seqs + off_x[k], len_x[k], seqs + off_y[k], len_y[k], sc, SA_FLAG_NO_TRACEBACK, &r);
+    const int rc1 = run_pair(ctx, KIND_SW, seqs + off_x[k], len_x[k], seqs + off_y[k], len_y[k], sc, al ? 0 : SA_FLAG_NO_TRACEBACK, &r);
     if (rc1 == SA_OK) {
       score[k] = (int32_t)r.score;
       end_i[k] = (int32_t)r.end_i;
       end_j[k] = (int32_t)r.end_j;
+      if (al) {
+        al->n_ops[k] = (int32_t)r.n_ops;
+        al->start_i[k] = (int32_t)r.start_i;
+        al->start_j[k] = (int32_t)r.start_j;
+        if (r.n_ops) memcpy(*al->pool + al->ops_off[k], r.ops, (size_t)r.n_ops);
+      }
       if (kernel_ms) *kernel_ms += r.kernel_fill_ms;
     } else if (rc1 == SA_ERR_INVALID_CODE) {
       score[k] = INT32_MIN;
@@ -883,6 +1004,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     }
     sa_free_result(&r);
   }
+  guard.keep = true;
   if (h_err) return fail(ctx, SA_ERR_INVALID_CODE, "at least one pair holds a residue outside the scoring alphabet (its score is INT32_MIN)");
   return SA_OK;
 }
@@ -963,6 +1085,9 @@ int sa_set_option(sa_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return SA_ERR_ARG;
   if (!strcmp(name, "persistent")) {
     c->persist = value != 0;
+  } else if (!strcmp(name, "batch_trace_budget_mb")) {
+    if (value < 1) return fail(c, SA_ERR_ARG, "batch_trace_budget_mb must be positive");
+    c->batch_trace_budget = (size_t)value << 20;
   } else if (!strcmp(name, "waves_per_simd")) {
     if (value < 1 || value > 4) return fail(c, SA_ERR_ARG, "waves_per_simd must be 1..4");
     c->wps = (int)value;
@@ -1026,5 +1151,15 @@ int sa_sw_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const in
                 int32_t* end_j, float* kernel_ms) {
   return run_batch(ctx, seqs, off_x, len_x, off_y, len_y, n_pairs, sc, score, end_i, end_j, kernel_ms);
 }
+
+int sa_sw_batch_align(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x, const int64_t* off_y,
+                      const int32_t* len_y, int64_t n_pairs, const sa_scoring* sc, int32_t* score, int32_t* end_i,
+                      int32_t* end_j, int32_t* start_i, int32_t* start_j, int64_t* ops_off, int32_t* n_ops,
+                      uint8_t** ops_pool, int64_t* ops_pool_bytes, float* kernel_ms) {
+  const BatchAlign al{start_i, start_j, ops_off, n_ops, ops_pool, ops_pool_bytes};
+  return run_batch(ctx, seqs, off_x, len_x, off_y, len_y, n_pairs, sc, score, end_i, end_j, kernel_ms, &al);
+}
+
+void sa_free_pool(uint8_t* pool) { free(pool); }
 
 }  // extern "C"

@@ -148,6 +148,11 @@ def load_library() -> C.CDLL:
     L.sa_stripe_fill.argtypes = [vp, C.c_int, vp, C.c_int64, vp, C.c_int64, C.POINTER(_Scoring), C.POINTER(_StripeDesc),
                                  C.POINTER(_Result)]
     L.sa_stripe_traceback.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(_Result)]
+    L.sa_sw_batch_align.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, C.POINTER(_Scoring), vp, vp, vp, vp, vp, vp, vp,
+                                    C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_float)]
+    L.sa_sw_batch_align.restype = C.c_int
+    L.sa_free_pool.argtypes = [vp]
+    L.sa_free_pool.restype = None
     for f in ("sa_set_stream", "sa_set_tuning", "sa_release_workspace", "sa_nw", "sa_sw", "sa_lcs", "sa_sw_batch",
               "sa_stripe_fill", "sa_stripe_traceback"):
         getattr(L, f).restype = C.c_int
@@ -306,6 +311,52 @@ class Engine:
         if rc and rc != SA_ERR_INVALID_CODE:
             raise SeqAlignError(rc, self.lib.sa_last_error(self.ctx).decode())
         return score, ei, ej, ms.value, rc
+
+    def sw_batch_align(self, seqs, off_x, len_x, off_y, len_y, mode="protein", gap_open=-5.0, gap_extend=-1.0):
+        """Full local alignments of many pairs (sa_sw_batch_align).  Returns a BatchAlignment:
+        per-pair score / end / start arrays and `ops(k)` = the op list of pair k, end -> start."""
+        seqs = _u8(seqs)
+        off_x = np.ascontiguousarray(off_x, np.int64)
+        off_y = np.ascontiguousarray(off_y, np.int64)
+        len_x = np.ascontiguousarray(len_x, np.int32)
+        len_y = np.ascontiguousarray(len_y, np.int32)
+        n = len(off_x)
+        i32 = lambda: np.zeros(n, np.int32)  # noqa: E731
+        score, ei, ej, si, sj, nops = i32(), i32(), i32(), i32(), i32(), i32()
+        ops_off = np.zeros(n, np.int64)
+        sc, keep = self._scoring(mode, gap_open, gap_extend)
+        ms = C.c_float(0)
+        pool = C.c_void_p()
+        pool_bytes = C.c_int64(0)
+        rc = self.lib.sa_sw_batch_align(self.ctx, seqs.ctypes.data, off_x.ctypes.data, len_x.ctypes.data, off_y.ctypes.data,
+                                        len_y.ctypes.data, n, C.byref(sc), score.ctypes.data, ei.ctypes.data, ej.ctypes.data,
+                                        si.ctypes.data, sj.ctypes.data, ops_off.ctypes.data, nops.ctypes.data,
+                                        C.byref(pool), C.byref(pool_bytes), C.byref(ms))
+        del keep
+        if rc and rc != SA_ERR_INVALID_CODE:
+            raise SeqAlignError(rc, self.lib.sa_last_error(self.ctx).decode())
+        nb = int(pool_bytes.value)
+        ops_pool = np.ctypeslib.as_array(C.cast(pool, C.POINTER(C.c_uint8)), shape=(nb,)).copy() if nb else np.zeros(0, np.uint8)
+        self.lib.sa_free_pool(pool)
+        return BatchAlignment(score, ei, ej, si, sj, ops_off, nops, ops_pool, ms.value, rc)
+
+
+@dataclass
+class BatchAlignment:
+    score: np.ndarray
+    end_i: np.ndarray
+    end_j: np.ndarray
+    start_i: np.ndarray
+    start_j: np.ndarray
+    ops_off: np.ndarray
+    n_ops: np.ndarray
+    ops_pool: np.ndarray
+    kernel_ms: float
+    rc: int
+
+    def ops(self, k) -> np.ndarray:
+        o = int(self.ops_off[k])
+        return self.ops_pool[o:o + int(self.n_ops[k])]
 
 
 _default: Optional[Engine] = None

@@ -77,3 +77,69 @@ def test_batch_invalid_residue_flags_only_that_pair(engine, oracle):
     for k in (0, 2):
         r = oracle.sw(pool[ox[k]:ox[k] + lx[k]], pool[oy[k]:oy[k] + ly[k]], "protein")
         assert (sc[k], ei[k], ej[k]) == (r.score, r.end[0], r.end[1])
+
+
+# ---- sa_sw_batch_align: full local alignments per pair ----
+def compare_align(engine, oracle, pool, ox, lx, oy, ly, mode="protein", go=-5.0, ge=-1.0):
+    b = engine.sw_batch_align(pool, ox, lx, oy, ly, mode, go, ge)
+    assert b.rc == 0
+    for k in range(len(ox)):
+        x = pool[ox[k]:ox[k] + lx[k]]
+        y = pool[oy[k]:oy[k] + ly[k]]
+        if lx[k] == 0 or ly[k] == 0:
+            assert b.score[k] == 0 and b.n_ops[k] == 0
+            continue
+        w = oracle.sw(x, y, mode, go, ge)
+        got = (int(b.score[k]), (int(b.end_i[k]), int(b.end_j[k])), (int(b.start_i[k]), int(b.start_j[k])))
+        assert got == (w.score, tuple(w.end), tuple(w.start)), (k, lx[k], ly[k], got, (w.score, w.end, w.start))
+        assert np.array_equal(b.ops(k), w.ops), (k, lx[k], ly[k])
+    return b
+
+
+def test_batch_align_all_row_groups(engine, oracle):
+    rng = np.random.default_rng(11)
+    lens = [(m, int(rng.integers(1, 500))) for m in list(range(1, 70, 3)) + list(range(120, 1030, 61)) + [63, 64, 65, 127, 128, 129, 1023, 1024]]
+    compare_align(engine, oracle, *make_pool(rng, lens))
+    compare_align(engine, oracle, *make_pool(rng, lens, PROT24, related=True))
+
+
+def test_batch_align_config5_shape_and_chunks(engine, oracle):
+    from sequencealigner_amd.synth import protein_pairs
+
+    pool, ox, lx, oy, ly = protein_pairs(200, seed=42)
+    b1 = compare_align(engine, oracle, pool, ox, lx, oy, ly)
+    # a tiny code budget cuts the same batch into many chunks: identical results
+    engine.set_option("batch_trace_budget_mb", 1)
+    try:
+        b2 = engine.sw_batch_align(pool, ox, lx, oy, ly)
+    finally:
+        engine.set_option("batch_trace_budget_mb", 32768)
+    for f in ("score", "end_i", "end_j", "start_i", "start_j", "n_ops", "ops_off"):
+        assert np.array_equal(getattr(b1, f), getattr(b2, f)), f
+    for k in range(len(ox)):
+        assert np.array_equal(b1.ops(k), b2.ops(k))
+
+
+def test_batch_align_gaps_dna_ties_and_edges(engine, oracle):
+    rng = np.random.default_rng(12)
+    lens = [(int(rng.integers(1, 300)), int(rng.integers(1, 300))) for _ in range(40)]
+    for go, ge in [(-10.0, -1.0), (-2.0, -2.0), (0.0, 0.0), (-1.0, -3.0)]:
+        compare_align(engine, oracle, *make_pool(rng, lens, related=True), go=go, ge=ge)
+    compare_align(engine, oracle, *make_pool(rng, lens, "ACGT", related=True), mode="dna")
+    compare_align(engine, oracle, *make_pool(rng, [(30, 30)] * 10 + [(200, 90)] * 3, "A"), mode="dna")  # tie storms
+    # no positive cell; empty sequences; a pair beyond the batch kernel's limits (single-pair path)
+    pool = np.frombuffer(b"AAAAAAAA" + b"CCCCCCCC" + b"ACGT" * 300 + b"ACGTT" * 260, np.uint8)
+    ox = np.array([0, 0, 0, 16])
+    lx = np.array([8, 0, 8, 1200], np.int32)
+    oy = np.array([8, 8, 8, 16 + 1200])
+    ly = np.array([8, 8, 0, 1300], np.int32)
+    compare_align(engine, oracle, pool, ox, lx, oy, ly, mode="dna")
+
+
+def test_batch_align_invalid_residue(engine, oracle):
+    pool = np.frombuffer(b"ACGTACGT" + b"ACGTxCGT" + b"ACGTACGA", np.uint8)
+    b = engine.sw_batch_align(pool, np.array([0, 0]), np.array([8, 8], np.int32), np.array([8, 16]), np.array([8, 8], np.int32), "dna")
+    assert b.rc == -2
+    assert b.score[0] == np.iinfo(np.int32).min and b.n_ops[0] == 0
+    w = oracle.sw(pool[0:8], pool[16:24], "dna")
+    assert b.score[1] == w.score and np.array_equal(b.ops(1), w.ops)
