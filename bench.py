@@ -70,8 +70,10 @@ def cpu_baseline(x, y, kind, sample):
 
 
 def bench_batch(args, rank, local_rank, world, dist, torch):
-    """Config 5: independent protein pairs (300-1000 aa, BLOSUM62, -5/-1), SW score + end cell.
-    Pairs are sharded contiguously over the ranks; no data-path collective."""
+    """Config 5: independent protein pairs (300-1000 aa, BLOSUM62, -5/-1), SW score + end cell
+    (--workload batch) or full local alignments (--workload batch-align: + direction codes, per-pair
+    traceback, op lists back on the host).  Pairs are sharded contiguously over the ranks; no
+    data-path collective."""
     import sequencealigner_amd as sa
     from sequencealigner_amd.synth import protein_pairs
 
@@ -79,6 +81,13 @@ def bench_batch(args, rank, local_rank, world, dist, torch):
     pool, ox, lx, oy, ly = protein_pairs(per_rank, seed=42 + rank)
     cells = int((lx.astype(np.int64) * ly.astype(np.int64)).sum())
     eng = sa.Engine(local_rank)
+    align = args.workload == "batch-align"
+
+    def run():
+        if align:
+            r = eng.sw_batch_align(pool, ox, lx, oy, ly, "protein")
+            return (r.score, r.end_i, r.end_j, r.kernel_ms, r.rc, r)
+        return eng.sw_batch(pool, ox, lx, oy, ly, "protein")
 
     def sync():
         torch.cuda.synchronize()
@@ -87,12 +96,12 @@ def bench_batch(args, rank, local_rank, world, dist, torch):
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        out = eng.sw_batch(pool, ox, lx, oy, ly, "protein")
+        out = run()
     sync()
     t0 = time.perf_counter()
     kms = 0.0
     for _ in range(args.steps):
-        out = eng.sw_batch(pool, ox, lx, oy, ly, "protein")
+        out = run()
         kms += out[3]
     sync()
     dt = time.perf_counter() - t0
@@ -106,21 +115,19 @@ def bench_batch(args, rank, local_rank, world, dist, torch):
         cells_all = float(cells)
     if rank == 0:
         line = {
-            "metric": "batched SW pairs/s (score + end cell)", "value": round(per_rank * world * args.steps / dt, 1),
+            "metric": "batched SW pairs/s (full local alignments)" if align else "batched SW pairs/s (score + end cell)", "value": round(per_rank * world * args.steps / dt, 1),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "strong",
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{per_rank * world} protein pairs, lengths U[300,1000], uniform residues, BLOSUM62 -5/-1, "
-                                   f"host buffers in (H2D inside the timed region)", "parallelism": f"pair sharding x{world}"},
+                                   f"host buffers in (H2D inside the timed region)" + (", op lists back on the host" if align else ""), "parallelism": f"pair sharding x{world}"},
             "gcups_end_to_end": round(cells_all * args.steps / dt / 1e9, 1),
             "gcups_kernel_only": round(cells_all * args.steps / (kms / 1e3) / 1e9, 1),
-            "roofline": {"bound": "valu", "achieved": round(cells_all * args.steps * 10 / (kms / 1e3) / 1e12 / world, 3),
+            "roofline": {"bound": "valu", "achieved": round(cells_all * args.steps * (14 if align else 10) / (kms / 1e3) / 1e12 / world, 3),
                          "peak": VALU_PEAK_TOPS, "unit": "T int32 lane-ops/s",
-                         "frac": round(cells_all * args.steps * 10 / (kms / 1e3) / 1e12 / world / VALU_PEAK_TOPS, 4),
-                         "traffic": None, "kernel": "sw_batch_kernel", "ops_per_cell": 10},
+                         "frac": round(cells_all * args.steps * (14 if align else 10) / (kms / 1e3) / 1e12 / world / VALU_PEAK_TOPS, 4),
+                         "traffic": None, "kernel": "sw_batch_kernel<K,TRACE>" if align else "sw_batch_kernel", "ops_per_cell": 14 if align else 10},
         }
-        if schedule_note:
-            line["config"]["schedule_note"] = schedule_note
         if not args.no_cpu and world == 1:
             from oracle import Oracle
 
@@ -131,6 +138,21 @@ def bench_batch(args, rank, local_rank, world, dist, torch):
             rc, sc, ei, ej = orc.sw_score_batch(pool, ox[:ns], lx[:ns], oy[:ns], ly[:ns], "protein", threads=threads)
             dtc = time.perf_counter() - t1
             assert rc == 0 and np.array_equal(sc, out[0][:ns]) and np.array_equal(ei, out[1][:ns]) and np.array_equal(ej, out[2][:ns])
+            if align:  # and the alignments of a few pairs against the oracle's full SW
+                for k in range(0, ns, max(1, ns // 16)):
+                    w = orc.sw(pool[ox[k]:ox[k] + lx[k]], pool[oy[k]:oy[k] + ly[k]], "protein")
+                    assert np.array_equal(out[5].ops(k), w.ops) and (out[5].start_i[k], out[5].start_j[k]) == tuple(w.start)
+            if align:  # the baseline of this workload is the full local alignment per pair, one core (the oracle's sw is serial)
+                na = min(400, ns)
+                t1 = time.perf_counter()
+                for k in range(na):
+                    orc.sw(pool[ox[k]:ox[k] + lx[k]], pool[oy[k]:oy[k] + ly[k]], "protein")
+                dta = time.perf_counter() - t1
+                line["cpu_baseline"] = {"value": round(na / dta, 1), "unit": "pairs/s", "cores": 1, "kind": "port",
+                                        "sample": f"first {na} pairs, full localalign (fill, prefix refill, traceback) one after the other "
+                                                  f"on one core, {dta:.1f} s; sampled alignments equal the GPU's"}
+                print(json.dumps(line), flush=True)
+                return
             line["cpu_baseline"] = {"value": round(ns / dtc, 1), "unit": "pairs/s", "cores": threads, "kind": "port",
                                     "sample": f"first {ns} pairs, one pair per thread on {threads} threads, {dtc:.1f} s; results equal the GPU's"}
         print(json.dumps(line), flush=True)
@@ -156,7 +178,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=1_000_000, help="query length (target is the mutated copy, ~same length)")
     ap.add_argument("--kind", default="nw", choices=["nw", "lcs", "sw"])
-    ap.add_argument("--workload", default="pair", choices=["pair", "batch"],
+    ap.add_argument("--workload", default="pair", choices=["pair", "batch", "batch-align"],
                     help="pair: one long pair (headline); batch: config 5, many protein pairs, SW score + end cell")
     ap.add_argument("--pairs", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample", type=int, default=40000)
@@ -180,7 +202,7 @@ def main():
     import sequencealigner_amd as sa
     from sequencealigner_amd.synth import dna_pair
 
-    if args.workload == "batch":
+    if args.workload in ("batch", "batch-align"):
         return bench_batch(args, rank, local_rank, world, dist, torch)
 
     x, y = dna_pair(args.size, seed=1234)

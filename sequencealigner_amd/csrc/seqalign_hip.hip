@@ -865,8 +865,9 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     if ((rc = ensure(ctx, ctx->b_seq, (size_t)pool_end + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_desc, desc.size() * sizeof(PairDesc)))) return rc;
     if ((rc = ensure(ctx, ctx->b_out, (size_t)n_pairs * 24 + 1024 + 2048))) return rc;
-    // aligning variant: cut the (K-sorted) pair list into chunks whose codes fit the trace budget;
-    // offsets of codes and op slots are relative to the chunk's buffers
+    // aligning variant: cut the (K-sorted) pair list into chunks whose codes fit the trace budget
+    // (code offsets are relative to the chunk's buffer); the op slots of ALL pairs live in one
+    // device image of the caller-ordered pool, which comes back in a single copy at the end
     struct Chunk {
       size_t lo, hi;
       long long trace_dwords, ops_bytes;
@@ -882,16 +883,16 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
           c = Chunk{q, q, 0, 0};
         }
         desc[q].off_trace = c.trace_dwords;
-        desc[q].off_ops = c.ops_bytes;
+        desc[q].off_ops = al->ops_off[desc[q].idx];
         c.trace_dwords += td;
         c.ops_bytes += ((long long)desc[q].m + desc[q].n + 3) & ~3LL;
         c.hi = q + 1;
       }
       chunks.push_back(c);
-      long long tmax = 0, omax = 0;
-      for (const Chunk& ch : chunks) tmax = std::max(tmax, ch.trace_dwords), omax = std::max(omax, ch.ops_bytes);
+      long long tmax = 0;
+      for (const Chunk& ch : chunks) tmax = std::max(tmax, ch.trace_dwords);
       if ((rc = ensure(ctx, ctx->trace, (size_t)tmax * 4))) return rc;
-      if ((rc = ensure(ctx, ctx->ops, (size_t)omax + 64))) return rc;
+      if ((rc = ensure(ctx, ctx->ops, (size_t)pool_total + 64))) return rc;
     }
     HIPCK(ctx, hipMemcpyAsync(ctx->b_seq.p, seqs, (size_t)pool_end, hipMemcpyHostToDevice, st));
     HIPCK(ctx, hipMemcpyAsync(ctx->b_desc.p, desc.data(), desc.size() * sizeof(PairDesc), hipMemcpyHostToDevice, st));
@@ -924,8 +925,6 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     a.start_i = d_si;
     a.start_j = d_sj;
     if (!al) chunks.push_back({0, desc.size(), 0, 0});
-    std::vector<uint8_t> stage;
-    std::vector<int> h_nops;
     float ms_total = 0;
     for (const auto& ch : chunks) {
       HIPCK(ctx, hipEventRecord(ctx->ev[0], st));
@@ -947,22 +946,12 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
       }
       HIPCK(ctx, hipGetLastError());
       HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
-      if (al) {  // the chunk's op slots come back in one copy and are scattered into the caller-ordered pool
-        stage.resize((size_t)ch.ops_bytes + 64);
-        h_nops.resize((size_t)n_pairs);
-        HIPCK(ctx, hipMemcpyAsync(stage.data(), ctx->ops.p, (size_t)ch.ops_bytes, hipMemcpyDeviceToHost, st));
-        HIPCK(ctx, hipMemcpyAsync(h_nops.data(), d_nops, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
-      }
       HIPCK(ctx, hipStreamSynchronize(st));
       float ms = 0;
       HIPCK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
       ms_total += ms;
-      if (al)
-        for (size_t q = ch.lo; q < ch.hi; ++q) {
-          const PairDesc& d = desc[q];
-          memcpy(*al->pool + al->ops_off[d.idx], stage.data() + d.off_ops, (size_t)h_nops[(size_t)d.idx]);
-        }
     }
+    if (al && pool_total > 0) HIPCK(ctx, hipMemcpyAsync(*al->pool, ctx->ops.p, (size_t)pool_total, hipMemcpyDeviceToHost, st));
     // results come back for every index; slots of pairs handled elsewhere are overwritten below
     std::vector<int> h_out((size_t)n_pairs * 6);
     HIPCK(ctx, hipMemcpyAsync(h_out.data(), d_score, (size_t)n_pairs * (al ? 24 : 12), hipMemcpyDeviceToHost, st));

@@ -336,9 +336,13 @@ class Engine:
         if rc and rc != SA_ERR_INVALID_CODE:
             raise SeqAlignError(rc, self.lib.sa_last_error(self.ctx).decode())
         nb = int(pool_bytes.value)
-        ops_pool = np.ctypeslib.as_array(C.cast(pool, C.POINTER(C.c_uint8)), shape=(nb,)).copy() if nb else np.zeros(0, np.uint8)
-        self.lib.sa_free_pool(pool)
-        return BatchAlignment(score, ei, ej, si, sj, ops_off, nops, ops_pool, ms.value, rc)
+        out = BatchAlignment(score, ei, ej, si, sj, ops_off, nops, np.zeros(0, np.uint8), ms.value, rc)
+        if nb:  # a view of the library's pool (no copy); freed when the BatchAlignment goes away
+            out.ops_pool = np.ctypeslib.as_array(C.cast(pool, C.POINTER(C.c_uint8)), shape=(nb,))
+            out._release = (self.lib.sa_free_pool, pool)
+        else:
+            self.lib.sa_free_pool(pool)
+        return out
 
 
 @dataclass
@@ -353,10 +357,18 @@ class BatchAlignment:
     ops_pool: np.ndarray
     kernel_ms: float
     rc: int
+    _release: Optional[tuple] = None  # ops_pool is valid as long as this object lives
 
     def ops(self, k) -> np.ndarray:
         o = int(self.ops_off[k])
-        return self.ops_pool[o:o + int(self.n_ops[k])]
+        return self.ops_pool[o:o + int(self.n_ops[k])].copy()
+
+    def __del__(self):
+        if self._release is not None:
+            free, pool = self._release
+            self._release = None
+            self.ops_pool = np.zeros(0, np.uint8)
+            free(pool)
 
 
 _default: Optional[Engine] = None
