@@ -47,6 +47,14 @@ typedef struct {
 int sah_read_fasta(const char* path, char** header, char** seq, int64_t* seq_len);
 void sah_free(void* p);
 
+/* Every record of a multi-FASTA file (the --batch extension of the CLI; the reference's reader
+ * above keeps the first header and concatenates all records, Q6).  Same line rules as
+ * sah_read_fasta inside a record: blank lines skipped, no '\r' stripping.  *headers and *seqs are
+ * malloc'd arrays of *n_records malloc'd strings, *lens a malloc'd array; release everything with
+ * sah_free_records. */
+int sah_read_fasta_records(const char* path, int64_t* n_records, char*** headers, char*** seqs, int64_t** lens);
+void sah_free_records(int64_t n_records, char** headers, char** seqs, int64_t* lens);
+
 /* copy the ID into buf (NUL-terminated, truncated to cap) */
 void sah_accession(const char* header, int mode, char* buf, int64_t cap);
 void sah_gene_symbol(const char* header, int mode, char* buf, int64_t cap);

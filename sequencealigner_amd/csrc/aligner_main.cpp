@@ -1,14 +1,21 @@
 // aligner_main.cpp -- the `aligner` CLI of the reference (main.cpp:1720-1839), same flags, same
 // exit codes, same result files; the DP runs on one MI355X through libseqalign_hip.so.
 // No MPI: one process drives the GPU.
+//
+// Extension: --batch treats --query / --target as multi-FASTA files with the same
+// number of records; record k of one is aligned with record k of the other and the usual result
+// files go to <outdir>/pair_<k>/ (k from 1), plus <outdir>/batch_summary.tsv.  --choice 2 runs all
+// pairs through one sa_sw_batch_align call; the other choices loop over the pairs.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
 #include <filesystem>
 #include <iostream>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "../../include/seqalign_hip.h"
 #include "../../include/seqalign_host.h"
@@ -22,6 +29,7 @@ struct Options {
   bool verbose = false, binary = false, txt = false;
   double gap_open = -5.0, gap_extend = -1.0;  // main.cpp:41-43
   int device = 0;
+  bool batch = false;
 };
 
 struct Seq {
@@ -100,6 +108,106 @@ void run_one(sa_ctx* ctx, int which, const Options& o, const Seq& q, const Seq& 
   sa_free_result(&r);
 }
 
+std::vector<Seq> read_records(const std::string& path) {
+  int64_t n = 0;
+  char **h = nullptr, **s = nullptr;
+  int64_t* len = nullptr;
+  if (sah_read_fasta_records(path.c_str(), &n, &h, &s, &len) != 0) throw std::runtime_error("Error: Unable to open " + path);
+  std::vector<Seq> out;
+  for (int64_t k = 0; k < n; ++k) out.push_back(Seq{h[k], std::string(s[k], (size_t)len[k])});
+  sah_free_records(n, h, s, len);
+  return out;
+}
+
+void run_batch_mode(sa_ctx* ctx, const Options& o) {
+  const std::vector<Seq> qs = read_records(o.query), ts = read_records(o.target);
+  if (qs.size() != ts.size())
+    throw std::runtime_error("--batch needs the same number of records in --query (" + std::to_string(qs.size()) + ") and --target (" +
+                             std::to_string(ts.size()) + ")");
+  const int64_t np = (int64_t)qs.size();
+  auto pair_dir = [&](int64_t k) { return o.outdir + "/pair_" + std::to_string(k + 1); };
+  for (int64_t k = 0; k < np; ++k) std::filesystem::create_directories(pair_dir(k));
+  FILE* sum = fopen((o.outdir + "/batch_summary.tsv").c_str(), "w");
+  if (!sum) throw std::runtime_error("Error: Unable to open " + o.outdir + "/batch_summary.tsv");
+  fprintf(sum, "pair\tqueryid\ttargetid\tquery_length\ttarget_length\tmethod\tscore\tend_i\tend_j\tstart_i\tstart_j\taligned_length\n");
+  auto ids = [&](int64_t k, char (&a)[256], char (&b)[256]) {
+    sah_accession(qs[k].header.c_str(), o.mode, a, sizeof a);
+    sah_accession(ts[k].header.c_str(), o.mode, b, sizeof b);
+  };
+  if (o.choice == 2 || o.choice == 4) {
+    // one engine call for every pair
+    std::string pool;
+    std::vector<int64_t> ox(np), oy(np), ops_off(np);
+    std::vector<int32_t> lx(np), ly(np), score(np), ei(np), ej(np), si(np), sj(np), nops(np);
+    for (int64_t k = 0; k < np; ++k) {
+      ox[k] = (int64_t)pool.size();
+      lx[k] = (int32_t)qs[k].residues.size();
+      pool += qs[k].residues;
+      oy[k] = (int64_t)pool.size();
+      ly[k] = (int32_t)ts[k].residues.size();
+      pool += ts[k].residues;
+    }
+    sa_scoring sc = *sa_builtin_scoring(o.mode);
+    sc.gap_open = o.gap_open;
+    sc.gap_extend = o.gap_extend;
+    uint8_t* ops_pool = nullptr;
+    int64_t pool_bytes = 0;
+    float kms = 0;
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    const int rc = sa_sw_batch_align(ctx, (const uint8_t*)pool.data(), ox.data(), lx.data(), oy.data(), ly.data(), np, &sc, score.data(),
+                                     ei.data(), ej.data(), si.data(), sj.data(), ops_off.data(), nops.data(), &ops_pool, &pool_bytes, &kms);
+    const auto t1 = std::chrono::high_resolution_clock::now();
+    if (rc != SA_OK && rc != SA_ERR_INVALID_CODE) throw std::runtime_error(std::string("GPU engine: ") + sa_last_error(ctx));
+    const int64_t ms_each = np ? std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count() / np : 0;
+    for (int64_t k = 0; k < np; ++k) {
+      char a[256], b[256];
+      ids(k, a, b);
+      if (score[k] == INT32_MIN) {  // what the reference prints for this pair (main.cpp:120-121, 1832-1838); no files
+        std::cerr << "Error: pair " << (k + 1) << ": invalid residue for --mode " << (o.mode == SA_MODE_DNA ? "dna" : "protein") << "\n";
+        fprintf(sum, "%lld\t%s\t%s\t%d\t%d\tlocal\tERROR\t\t\t\t\t\n", (long long)k + 1, a, b, lx[k], ly[k]);
+        continue;
+      }
+      const std::string dir = pair_dir(k);
+      sah_job job{};
+      job.outdir = dir.c_str();
+      job.header1 = qs[k].header.c_str();
+      job.header2 = ts[k].header.c_str();
+      job.mode = o.mode;
+      job.gap_open = o.gap_open;
+      job.gap_extend = o.gap_extend;
+      job.x = (const uint8_t*)pool.data() + ox[k];
+      job.m = lx[k];
+      job.y = (const uint8_t*)pool.data() + oy[k];
+      job.n = ly[k];
+      job.score = score[k];
+      job.end_i = ei[k];
+      job.end_j = ej[k];
+      job.ops = ops_pool + ops_off[k];
+      job.n_ops = nops[k];
+      job.time_ms = ms_each;
+      job.verbose = o.verbose;
+      sah_write_local(&job);
+      fprintf(sum, "%lld\t%s\t%s\t%d\t%d\tlocal\t%d\t%d\t%d\t%d\t%d\t%d\n", (long long)k + 1, a, b, lx[k], ly[k], score[k], ei[k], ej[k],
+              si[k], sj[k], nops[k]);
+    }
+    sa_free_pool(ops_pool);
+  }
+  for (int which : {1, 3}) {
+    if (o.choice != which && o.choice != 4) continue;
+    for (int64_t k = 0; k < np; ++k) {
+      Options ok = o;
+      ok.outdir = pair_dir(k);
+      ok.binary = ok.txt = false;
+      try {
+        run_one(ctx, which, ok, qs[k], ts[k]);
+      } catch (const std::exception& e) {
+        std::cerr << "Error: pair " << (k + 1) << ": " << e.what() << "\n";
+      }
+    }
+  }
+  fclose(sum);
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -143,6 +251,8 @@ int main(int argc, char** argv) {
         o.gap_extend = std::stod(argv[++i]);
       } else if (arg == "--device" && i + 1 < argc) {  // extension: which GPU
         o.device = std::stoi(argv[++i]);
+      } else if (arg == "--batch") {  // extension: multi-FASTA, record k vs record k
+        o.batch = true;
       } else {
         std::cerr << "Unknown option: " << arg << "\n";
         return 1;
@@ -153,6 +263,13 @@ int main(int argc, char** argv) {
       return 1;
     }
     std::filesystem::create_directories(o.outdir);
+    if (o.batch && o.choice >= 1 && o.choice <= 4) {
+      ctx = sa_create(o.device);
+      if (!ctx) throw std::runtime_error("no gfx950 GPU available (this build has no CPU path)");
+      run_batch_mode(ctx, o);
+      sa_destroy(ctx);
+      return 0;
+    }
     const Seq q = read_fasta(o.query), t = read_fasta(o.target);
     if (o.choice >= 1 && o.choice <= 4) {
       ctx = sa_create(o.device);

@@ -272,6 +272,50 @@ int sah_read_fasta(const char* path, char** header, char** seq, int64_t* seq_len
   return 0;
 }
 
+int sah_read_fasta_records(const char* path, int64_t* n_records, char*** headers, char*** seqs, int64_t** lens) {
+  std::ifstream f(path);
+  if (!f) return -1;
+  std::vector<std::string> hs, ss;
+  std::string line;
+  while (std::getline(f, line)) {
+    if (line.empty()) continue;
+    if (line[0] == '>') {
+      hs.push_back(line.substr(1));
+      ss.emplace_back();
+      continue;
+    }
+    if (ss.empty()) {  // sequence lines before any header: one unnamed record
+      hs.emplace_back();
+      ss.emplace_back();
+    }
+    ss.back() += line;
+  }
+  const size_t n = hs.size();
+  *n_records = (int64_t)n;
+  *headers = (char**)malloc((n + 1) * sizeof(char*));
+  *seqs = (char**)malloc((n + 1) * sizeof(char*));
+  *lens = (int64_t*)malloc((n + 1) * sizeof(int64_t));
+  for (size_t k = 0; k < n; ++k) {
+    (*headers)[k] = (char*)malloc(hs[k].size() + 1);
+    memcpy((*headers)[k], hs[k].c_str(), hs[k].size() + 1);
+    (*seqs)[k] = (char*)malloc(ss[k].size() + 1);
+    memcpy((*seqs)[k], ss[k].data(), ss[k].size());
+    (*seqs)[k][ss[k].size()] = 0;
+    (*lens)[k] = (int64_t)ss[k].size();
+  }
+  return 0;
+}
+
+void sah_free_records(int64_t n_records, char** headers, char** seqs, int64_t* lens) {
+  for (int64_t k = 0; k < n_records; ++k) {
+    free(headers[k]);
+    free(seqs[k]);
+  }
+  free(headers);
+  free(seqs);
+  free(lens);
+}
+
 void sah_accession(const char* header, int mode, char* buf, int64_t cap) {
   const std::string a = accession(header, mode);
   snprintf(buf, (size_t)cap, "%s", a.c_str());

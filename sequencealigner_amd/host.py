@@ -58,6 +58,23 @@ def read_fasta(path):
     return header, seq
 
 
+def read_fasta_records(path):
+    """every record of a multi-FASTA file: [(header, residues bytes)] (sah_read_fasta_records)"""
+    L = load_host_library()
+    L.sah_read_fasta_records.argtypes = [C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.POINTER(C.c_char_p)),
+                                         C.POINTER(C.POINTER(C.c_void_p)), C.POINTER(C.POINTER(C.c_int64))]
+    L.sah_read_fasta_records.restype = C.c_int
+    L.sah_free_records.argtypes = [C.c_int64, C.POINTER(C.c_char_p), C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    L.sah_free_records.restype = None
+    n = C.c_int64()
+    hs, ss, ls = C.POINTER(C.c_char_p)(), C.POINTER(C.c_void_p)(), C.POINTER(C.c_int64)()
+    if L.sah_read_fasta_records(str(path).encode(), C.byref(n), C.byref(hs), C.byref(ss), C.byref(ls)) != 0:
+        raise FileNotFoundError(f"Error: Unable to open {path}")
+    out = [(hs[k].decode("latin-1"), C.string_at(ss[k], ls[k])) for k in range(n.value)]
+    L.sah_free_records(n, hs, ss, ls)
+    return out
+
+
 def accession(header: str, mode: str) -> str:
     buf = C.create_string_buffer(4096)
     load_host_library().sah_accession(header.encode("latin-1"), MODES[mode], buf, 4096)

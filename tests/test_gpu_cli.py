@@ -76,3 +76,49 @@ def test_cli_dp_dumps_match_reference_layout(tmp_path):
     rows, cols = np.frombuffer(raw[:8], np.int32)
     assert (rows, cols) == (len(x) + 1, len(y) + 1)
     assert np.array_equal(np.frombuffer(raw[8:], np.int32).reshape(rows, cols), orc.nw(x, y, "dna", keep_dp=True).dp)
+
+
+def test_cli_batch_mode_equals_single_pair_runs(tmp_path):
+    """--batch (extension): every pair's files equal what the single-pair CLI writes for that pair
+    (time_ms aside), for all three methods; the summary lists every pair."""
+    import numpy as np
+
+    from conftest import PROT20, mutate, rand_seq
+
+    rng = np.random.default_rng(5)
+    pairs = []
+    for k, m in enumerate([40, 333, 700, 1100, 64]):
+        x = rand_seq(rng, m, PROT20)
+        y = mutate(rng, x, PROT20, 0.2, 0.05, 0.05) if k != 4 else rand_seq(rng, 90, PROT20)
+        pairs.append((f"sp|Q{k:05d}|QRY{k}_TEST query {k} GN=GQ{k} PE=1", x, f"sp|T{k:05d}|TGT{k}_TEST target {k} GN=GT{k}", y))
+    q, t = tmp_path / "q.fa", tmp_path / "t.fa"
+    q.write_text("".join(f">{h}\n{x}\n" for h, x, _, _ in pairs))
+    t.write_text("".join(f">{h}\n{y[:len(y) // 2]}\n{y[len(y) // 2:]}\n" for _, _, h, y in pairs))
+    out = tmp_path / "batch"
+    r = subprocess.run([str(PKG / "aligner"), "--query", str(q), "--target", str(t), "--choice", "4", "--mode", "protein",
+                        "--outdir", str(out), "--batch"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stderr == "", r.stderr
+    for k, (hq, x, ht, y) in enumerate(pairs):
+        sq, st = tmp_path / f"q{k}.fa", tmp_path / f"t{k}.fa"
+        sq.write_text(f">{hq}\n{x}\n")
+        st.write_text(f">{ht}\n{y}\n")
+        single = tmp_path / f"single{k}"
+        r1 = subprocess.run([str(PKG / "aligner"), "--query", str(sq), "--target", str(st), "--choice", "4", "--mode", "protein",
+                             "--outdir", str(single)], capture_output=True, text=True, timeout=120)
+        assert r1.returncode == 0 and r1.stderr == ""
+        names = sorted(p.name for p in single.iterdir())
+        assert names == sorted(p.name for p in (out / f"pair_{k + 1}").iterdir())
+        for name in names:
+            a, b = (single / name).read_text(), (out / f"pair_{k + 1}" / name).read_text()
+            if name.endswith(".json"):
+                ja, jb = json.loads(a), json.loads(b)
+                ja.pop("time_ms"), jb.pop("time_ms")
+                assert ja == jb, (k, name)
+            else:
+                assert a == b, (k, name)
+    rows = (out / "batch_summary.tsv").read_text().splitlines()
+    assert len(rows) == 1 + len(pairs) and rows[1].split("\t")[:3] == ["1", "Q00000", "T00000"]
+    # unequal record counts: caught error, exit 0 (main.cpp:1832-1838 behaviour)
+    r = subprocess.run([str(PKG / "aligner"), "--query", str(q), "--target", str(tmp_path / "t0.fa"), "--choice", "2", "--mode",
+                        "protein", "--outdir", str(tmp_path / "bad"), "--batch"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0 and r.stderr.startswith("Error: --batch needs the same number of records")
