@@ -96,7 +96,11 @@ int sa_release_workspace(sa_ctx* ctx);
 int sa_set_tuning(sa_ctx* ctx, int rows_per_lane, int tile_steps);
 /* engine options: "persistent" 0/1 (fill as one persistent strip-pipelined launch instead of one
  * launch per tile diagonal; same results), "waves_per_simd" 1..4 (grid of the persistent launch),
- * "batch_trace_budget_mb" (sa_sw_batch_align: device bytes of direction codes per chunk) */
+ * "batch_trace_budget_mb" (sa_sw_batch_align: device bytes of direction codes per chunk),
+ * "trace_budget_mb" (single pair: bytes of 2-bit codes a call may hold, 0 = 88 % of the device; a pair
+ * whose codes exceed it is filled with checkpoints -- the bottom row of every strip -- and the
+ * traceback recomputes the strips it crosses, a band at a time: same results, about twice the fill
+ * work, and e.g. 2 Mb x 2 Mb on one GPU), "checkpoint_band" N > 0 (always take that path, N strips per band) */
 int sa_set_option(sa_ctx* ctx, const char* name, int64_t value);
 
 /* The reference's two built-in scoring schemes with default penalties -5/-1

@@ -51,17 +51,20 @@ struct FillArgs {
   const int2* lb;        // left border per matrix row i = 0..m: (H[i][0], E[i][0]) of this stripe
   int2* rb;              // optional: right border out, (H[i][n], E[i][n]) for i = 1..m (column stripes)
   int* dp;               // optional (DUMP): (m+1)x(n+1) row-major S / L matrix, interior cells
-  int* botH;             // [2][NP]  bottom row H of strip s lives in buffer s&1, index p = c+64
-  int* botF;             // [2][NP]
+  int* botH;             // [ring][NP]  bottom row H of strip s lives in slot wr_slot(s), index p = c+64
+  int* botF;             // [ring][NP]
+  int ring;              // 2: strips alternate between two slots; S+1: every strip keeps its own (checkpoints)
   int* state;            // [S][NF][64] lane state carried from tile to tile
-  uint32_t* trace;       // [S][W][64][K]
+  uint32_t* trace;       // [S][W][64][K]; null: codes are computed but not stored (checkpoint pass)
+  int trace_s0;          // strip whose codes sit at the start of `trace` (banded recomputation)
   int* rowbest;          // SW: best score per row
   int* rowbestc;         // SW: first column (0-based) attaining it
   int* score_out;        // NW/LCS: H[m][n]
   int d, s_lo, s_hi;     // launch index, first / last strip of this launch
   // persistent strip pipeline (fill_persistent): one launch, hand-off every 64 steps
   int* prog;             // [S] blocks of 64 steps completed per strip (zeroed before the launch)
-  int* ticket;           // next strip to hand out (zeroed)
+  int* ticket;           // next strip to hand out, relative to s_first (zeroed)
+  int s_first, s_last;   // strips this persistent launch sweeps (the whole matrix: 0 .. S-1)
   int* err;              // set to 1 when a bounded spin ran out (zeroed)
   int spin_limit;        // polls before a waiting wave gives up
   // persistent pipeline over column stripes: borders cross GPUs while the kernel runs
@@ -78,6 +81,11 @@ struct FillArgs {
 // (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads", row 1).
 __device__ __forceinline__ int ld_coherent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_coherent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// slot of the bottom-row buffers strip s reads (the row above it; row 0 of the matrix sits in the
+// last slot) and writes
+__device__ __forceinline__ int rd_slot(const FillArgs& a, int s) { return a.ring == 2 ? ((s & 1) ^ 1) : (s == 0 ? a.ring - 1 : s - 1); }
+__device__ __forceinline__ int wr_slot(const FillArgs& a, int s) { return a.ring == 2 ? (s & 1) : s; }
 
 __device__ __forceinline__ int dpp_shr1(int old, int src) {  // lane l <- src of lane l-1, lane 0 <- old
   return __builtin_amdgcn_update_dpp(old, src, 0x138, 0xf, 0xf, false);
@@ -256,8 +264,8 @@ __device__ __forceinline__ void load_block_inputs(const FillArgs& a, const int s
                                                   int& ibF, int& yb) {
   using G = Geo<KIND, K>;
   constexpr bool PERSIST = (FLAGS & FLAG_PERSIST) != 0;
-  const int* rdH = a.botH + (size_t)((s & 1) ^ 1) * a.NP;
-  const int* rdF = a.botF + (size_t)((s & 1) ^ 1) * a.NP;
+  const int* rdH = a.botH + (size_t)rd_slot(a, s) * a.NP;
+  const int* rdF = a.botF + (size_t)rd_slot(a, s) * a.NP;
   ibF = 0;
   if (PERSIST) {
     ibH = ld_coherent(rdH + Tb + 64 + lane);
@@ -286,10 +294,10 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
   // loop-carried copies, and the compiler waits for a load before it copies its result).  The SW
   // body is too large for that (it spills), so it keeps the loop.
   constexpr int kUnroll = (PERSIST && KIND != KIND_SW) ? kSubUnroll : 1;
-  int* wrH = a.botH + (size_t)(s & 1) * a.NP;
-  int* wrF = a.botF + (size_t)(s & 1) * a.NP;
+  int* wrH = a.botH + (size_t)wr_slot(a, s) * a.NP;
+  int* wrF = a.botF + (size_t)wr_slot(a, s) * a.NP;
   int obH = 0, obF = 0;
-  uint32_t* tdst = a.trace + (((size_t)s * a.W + (Tb >> 4)) * 64 + lane) * K;
+  uint32_t* tdst = a.trace + (((size_t)(s - a.trace_s0) * a.W + (Tb >> 4)) * 64 + lane) * K;
 #pragma unroll kUnroll
   for (int sub = 0; sub < 4; ++sub) {
     uint32_t tacc[K];
@@ -299,7 +307,7 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
 #pragma unroll
     for (int u = 0; u < 16; ++u)
       lane_step<KIND, K, BND, FLAGS>(st, ibH, ibF, yb, obH, obF, tacc, u, ldsLane, xr, a, cbase + u, dprow);
-    store_trace<K>(tdst, tacc);
+    if (a.trace) store_trace<K>(tdst, tacc);
     tdst += 64 * K;
     hook(sub);
   }
@@ -494,8 +502,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
   while (true) {
     int s = 0;
     if (lane == 0) s = atomicAdd(a.ticket, 1);
-    s = __builtin_amdgcn_readfirstlane(s);
-    if (s >= a.S) break;
+    s = a.s_first + __builtin_amdgcn_readfirstlane(s);
+    if (s > a.s_last) break;
     const int rowg = s * 64 + lane;
     const int r0 = rowg * K;
     uint32_t xr[K];
@@ -548,7 +556,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
     int vzero;  // 0 in a VGPR the compiler cannot see through
     asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
     int* const my_prog = a.prog + s;
-    const int* const up_prog = a.prog + (s > 0 ? s - 1 : 0);
+    const bool has_up = s > a.s_first;  // the first strip of the launch finds its row above complete
+    const int* const up_prog = a.prog + (has_up ? s - 1 : s);
 #pragma unroll 1
     for (int b = 0; b < NB; ++b) {
       const int Tb = 64 * b;
@@ -558,7 +567,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
         ibF = nF;
         yb = (KIND != KIND_LCS) ? ny * G::ROWB : ny;
       } else {
-        if (s > 0) {
+        if (has_up) {
           const int need = min(b + 2, NB);
           int spins = 0;
           while (seen < need) {
@@ -595,7 +604,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
           pv = ld_coherent(up_prog + vzero);
         } else if (sub == 2) {
           seen = max(seen, __builtin_amdgcn_readfirstlane(pv));
-          if (b + 1 < NB && (s == 0 || seen >= min(b + 3, NB))) {
+          if (b + 1 < NB && (!has_up || seen >= min(b + 3, NB))) {
             asm volatile("" ::: "memory");
             load_block_inputs<KIND, K, PF, true>(a, s, Tb + 64, lane, nH, nF, ny);
             have_next = true;
@@ -692,6 +701,9 @@ struct TraceArgs {
   int kind, m, n, K, W;
   int start_i, start_j;   // < 0: default start (NW/LCS: (m,n); SW: the reduced best cell)
   int stop_at_col0;       // column stripes (not the first): stop when j reaches 0 and hand i over
+  int i_min;              // banded recomputation: `trace` holds the codes of matrix rows i_min+1 .. only; the
+                          // walk stops when it reaches row i_min (with j > 0) and hands (i, j) over
+  long long nops0;        // moves already written to `ops` by the walks over the bands below
   const uint32_t* trace;
   const int* sw_best;                  // SW: best score (device)
   const unsigned long long* sw_pos;    // SW: (i<<32)|j of the end cell (device)
@@ -774,14 +786,15 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
     a.hdr[1] = i;
     a.hdr[2] = j;
   }
-  long long nops = 0;
+  long long nops = a.nops0;
+  const int i_min = a.i_min;
   uint32_t warm = 0;
   bool have_next = false;  // nw holds the window of entry cell (pi, pj)
   int pi = 0, pj = 0;
   TraceWindow nw{0, 0, 0, 0};
   bool stopped = false;
-  while (i > 0 && j > 0 && !stopped) {
-    if (window_ok(i, j)) {
+  while (i > i_min && j > 0 && !stopped) {
+    if (window_ok(i - i_min, j)) {
       // ---- fast path: 64 rows per memory round trip, the next window already in flight ----
       TraceWindow w;
       int j0, o;
@@ -790,15 +803,15 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
         j0 = pj;
         o = j - pj;
       } else {
-        w = load_trace_window(a.trace, i, j, d, lgK, a.W);
+        w = load_trace_window(a.trace, i - i_min, j, d, lgK, a.W);
         j0 = j;
         o = 0;
       }
-      have_next = window_ok(i - 64, j - 64);
+      have_next = window_ok(i - 64 - i_min, j - 64);
       if (have_next) {
         pi = i - 64;
         pj = j - 64;
-        nw = load_trace_window(a.trace, pi, pj, d, lgK, a.W);
+        nw = load_trace_window(a.trace, pi - i_min, pj, d, lgK, a.W);
       }
       int dcur = 0;
       const int o_in = o;
@@ -837,12 +850,12 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
       if (dcur != 0 || o != o_in || stopped) continue;
     }
     // ---- generic path (borders, SW tails, tiny matrices): one run per memory round trip ----
-    const bool vM = (i - d >= 1) && (j - d >= 1);
+    const bool vM = (i - d > i_min) && (j - d >= 1);
     const bool vE = (j - d >= 1);
-    const bool vF = (i - d >= 1);
-    const uint32_t cM = vM ? trace_code(a.trace, i - d, j - d, lgK, a.W, tagged) : 3u;
-    const uint32_t cE = vE ? trace_code(a.trace, i, j - d, lgK, a.W, tagged) : 3u;
-    const uint32_t cF = vF ? trace_code(a.trace, i - d, j, lgK, a.W, tagged) : 3u;
+    const bool vF = (i - d > i_min);
+    const uint32_t cM = vM ? trace_code(a.trace, i - d - i_min, j - d, lgK, a.W, tagged) : 3u;
+    const uint32_t cE = vE ? trace_code(a.trace, i - i_min, j - d, lgK, a.W, tagged) : 3u;
+    const uint32_t cF = vF ? trace_code(a.trace, i - d - i_min, j, lgK, a.W, tagged) : 3u;
     const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cM);
     if (c0 == 3u) break;  // SW stop cell ('X', main.cpp:1233)
     unsigned long long run;
@@ -869,7 +882,10 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
     }
   }
   if (warm == 0xffffffffu) a.hdr[7] = warm;  // keeps the warming loads alive; never true (codes are < 4)
-  if (a.kind != KIND_SW && a.stop_at_col0) {
+  if (i > 0 && j > 0) {
+    // NW / LCS: the walk reached the top row of a recomputed band; the host continues with the band
+    // above from (i, j).  SW: it stopped at its 'X' cell.
+  } else if (a.kind != KIND_SW && a.stop_at_col0) {
     if (i == 0) {  // row 0 of the matrix: left moves to the stripe's edge
       for (long long q = d; q < j; q += 64) a.ops[nops + q] = 1;
       nops += j;

@@ -50,7 +50,14 @@ struct sa_ctx {
   // geometry of the last fill, for the traceback that follows it
   struct {
     int valid = 0, kind = 0, m = 0, n = 0, K = 0, W = 0, first_stripe = 1;
+    // checkpointed fill: the codes did not fit, only every strip's bottom row was kept; the
+    // traceback recomputes `band` strips at a time from these arguments
+    int ckpt = 0, band = 0, S = 0;
+    sa::FillArgs args;
+    size_t lds = 0;
   } last;
+  size_t trace_budget = 0;  // bytes of codes one call may hold; 0 = 88 % of the device memory
+  int force_band = 0;       // > 0: always checkpoint and recompute this many strips at a time
 };
 
 namespace {
@@ -336,7 +343,31 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   if ((rc = ensure(ctx, ctx->xenc, rows_pad + 64))) return rc;
   if ((rc = ensure(ctx, ctx->yenc, (size_t)Tend + 256))) return rc;
   if (first && (rc = ensure(ctx, ctx->lbuf, ((size_t)m + 1) * 8))) return rc;
-  if ((rc = ensure(ctx, ctx->bot, (size_t)4 * NP * 4))) return rc;
+  // Codes: 2 bits per cell.  When they do not fit the budget (2 Mb x 2 Mb is 1 TB) the fill keeps the
+  // bottom row of EVERY strip instead (checkpoints, 8 B per column per strip) and the traceback
+  // recomputes the strips it walks through, a band at a time.  Score-only calls
+  // store no codes at all.
+  const size_t strip_trace_bytes = (size_t)W * 64 * K * 4;
+  const bool no_tb = (flags & SA_FLAG_NO_TRACEBACK) != 0 && !sd;
+  size_t budget = ctx->trace_budget;
+  if (!budget) {
+    size_t free_b = 0, total_b = 0;
+    HIPCK(ctx, hipMemGetInfo(&free_b, &total_b));
+    budget = (size_t)((double)total_b * 0.88);
+  }
+  const bool ckpt = !no_tb && !sd && ((size_t)S * strip_trace_bytes > budget || (ctx->force_band > 0 && persist));
+  if (ckpt && !persist)
+    return fail(ctx, SA_ERR_NOMEM, "%.1f GB of traceback codes exceed the budget and checkpointed recomputation needs the persistent "
+                "schedule (integral gaps, no matrix dump)", (double)S * strip_trace_bytes / 1e9);
+  const int ring = ckpt ? S + 1 : 2;
+  int band = S;
+  if (ckpt) {
+    const size_t ck_bytes = (size_t)2 * ring * NP * 4;
+    if (ck_bytes + strip_trace_bytes > budget) return fail(ctx, SA_ERR_NOMEM, "checkpoint rows (%.1f GB) do not fit the budget", ck_bytes / 1e9);
+    band = (int)std::max<size_t>(1, std::min<size_t>((size_t)S, (budget - ck_bytes) / strip_trace_bytes));
+    if (ctx->force_band > 0) band = std::min(band, ctx->force_band);
+  }
+  if ((rc = ensure(ctx, ctx->bot, (size_t)2 * ring * NP * 4))) return rc;
   if ((rc = ensure(ctx, ctx->state, (size_t)S * NF * 64 * 4))) return rc;
   if ((rc = ensure(ctx, ctx->small, 256))) return rc;
   const size_t pbuf_ints = (size_t)S + 64 + (size_t)n_chunks;
@@ -348,8 +379,8 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   }
   if (kind == KIND_SW && (rc = ensure(ctx, ctx->rowbest, (size_t)2 * m * 4))) return rc;
   if (dump && (rc = ensure(ctx, ctx->dpbuf, ((size_t)m + 1) * ((size_t)n + 1) * 4))) return rc;
-  const size_t trace_bytes = (size_t)S * W * 64 * K * 4;
-  if ((rc = ensure(ctx, ctx->trace, trace_bytes))) return rc;
+  const size_t trace_bytes = no_tb ? 0 : (size_t)band * strip_trace_bytes;
+  if (trace_bytes && (rc = ensure(ctx, ctx->trace, trace_bytes))) return rc;
 
   // host-side encoding (O(m+n))
   std::vector<uint8_t> xe(rows_pad + 64, 0), ye((size_t)Tend + 256, 0);
@@ -386,15 +417,23 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
     lb = (const int2*)sd->left;
   }
   int* botH = (int*)ctx->bot.p;
-  int* botF = botH + (size_t)2 * NP;
-  // strip 0 reads ring buffer 1: row 0 of the matrix, H[0][j] at p = j + 63
-  HIPCK(ctx, hipMemsetAsync(botH, 0, (size_t)2 * NP * 4, st));
-  HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)botF, kind == KIND_NW ? kNeg : 0, (size_t)2 * NP, st));
+  int* botF = botH + (size_t)ring * NP;
+  // strip 0 reads the last slot: row 0 of the matrix, H[0][j] at p = j + 63.  Every other slot is
+  // written by its strip before the strip below reads it.
+  int* row0H = botH + (size_t)(ring - 1) * NP;
+  int* row0F = botF + (size_t)(ring - 1) * NP;
+  if (ring == 2) {
+    HIPCK(ctx, hipMemsetAsync(botH, 0, (size_t)2 * NP * 4, st));
+    HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)botF, kind == KIND_NW ? kNeg : 0, (size_t)2 * NP, st));
+  } else {
+    HIPCK(ctx, hipMemsetAsync(row0H, 0, (size_t)NP * 4, st));
+    HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)row0F, kind == KIND_NW ? kNeg : 0, (size_t)NP, st));
+  }
   std::vector<int> rowb4;
   if (kind == KIND_NW) {
     rowb4.resize((size_t)n);
     for (int j = 0; j < n; ++j) rowb4[j] = 4 * rowb[j + 1];
-    HIPCK(ctx, hipMemcpyAsync(botH + NP + 64, rowb4.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+    HIPCK(ctx, hipMemcpyAsync(row0H + 64, rowb4.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
   }
   HIPCK(ctx, hipMemsetAsync(ctx->small.p, 0, 256, st));
   int* d_score = (int*)ctx->small.p;                                           // [0]   NW/LCS score / SW best
@@ -426,7 +465,11 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   a.botH = botH;
   a.botF = botF;
   a.state = (int*)ctx->state.p;
-  a.trace = (uint32_t*)ctx->trace.p;
+  a.trace = (ckpt || no_tb) ? nullptr : (uint32_t*)ctx->trace.p;  // checkpoint pass / score only: no codes
+  a.trace_s0 = 0;
+  a.ring = ring;
+  a.s_first = 0;
+  a.s_last = S - 1;
   a.rowbest = (int*)ctx->rowbest.p;
   a.rowbestc = a.rowbest ? a.rowbest + m : nullptr;
   a.score_out = d_score;
@@ -525,11 +568,107 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   ctx->last.K = K;
   ctx->last.W = W;
   ctx->last.first_stripe = first ? 1 : 0;
+  ctx->last.ckpt = ckpt ? 1 : 0;
+  ctx->last.band = band;
+  ctx->last.S = S;
+  ctx->last.args = a;
+  ctx->last.lds = lds;
+  return SA_OK;
+}
+
+// Traceback after a checkpointed fill: from the start cell upwards, recompute the codes of `band`
+// strips at a time (the persistent kernel restricted to those strips, reading the kept bottom row
+// of the strip above the band) and let the walker cross the band; it hands (i, j) over at the
+// band's top row.  Same op list as the one-slab traceback; costs a second fill of the rows walked.
+int traceback_ckpt(sa_ctx* ctx, int start_i, int start_j, sa_result* out) {
+  hipStream_t st = ctx->stream;
+  const int kind = ctx->last.kind, m = ctx->last.m, n = ctx->last.n, K = ctx->last.K, S = ctx->last.S, B = ctx->last.band;
+  struct {
+    int score;
+    int pad;
+    unsigned long long pos;
+    int rest[40];
+  } h_sc{};
+  HIPCK(ctx, hipMemcpyAsync(&h_sc, ctx->small.p, sizeof h_sc, hipMemcpyDeviceToHost, st));
+  HIPCK(ctx, hipStreamSynchronize(st));
+  if (h_sc.rest[36] != 0) return fail(ctx, SA_ERR_HIP, "persistent fill: a bounded wait on the previous strip expired (results discarded)");
+  int i = m, j = n;
+  if (start_i >= 0) {
+    i = start_i, j = start_j;
+  } else if (kind == KIND_SW) {
+    i = h_sc.score > 0 ? (int)(h_sc.pos >> 32) : 0;
+    j = h_sc.score > 0 ? (int)(h_sc.pos & 0xffffffffu) : 0;
+  }
+  out->score = h_sc.score;
+  out->end_i = i;
+  out->end_j = j;
+  long long nops = 0;
+  FillArgs a = ctx->last.args;
+  a.trace = (uint32_t*)ctx->trace.p;
+  long long* d_hdr = (long long*)((char*)ctx->small.p + 64);
+  int* d_err = (int*)ctx->small.p + 40;
+  while (i > 0 && j > 0) {
+    const int s_hi = (i - 1) / (64 * K);
+    const int s_lo = std::max(0, s_hi - B + 1);
+    HIPCK(ctx, hipMemsetAsync(ctx->pbuf.p, 0, ((size_t)S + 64) * 4, st));
+    a.s_first = s_lo;
+    a.s_last = s_hi;
+    a.trace_s0 = s_lo;
+    const dim3 grid(std::min((s_hi - s_lo + 1 + kWavesPerBlock - 1) / kWavesPerBlock, ctx->n_cu * std::max(1, ctx->wps)));
+    if (kind == KIND_NW)
+      launch_persistent<KIND_NW>(K, grid, ctx->last.lds, st, a);
+    else if (kind == KIND_SW)
+      launch_persistent<KIND_SW>(K, grid, ctx->last.lds, st, a);
+    else
+      launch_persistent<KIND_LCS>(K, grid, ctx->last.lds, st, a);
+    ++out->n_launches;
+    TraceArgs t{};
+    t.kind = kind;
+    t.m = m;
+    t.n = n;
+    t.K = K;
+    t.W = ctx->last.W;
+    t.start_i = i;
+    t.start_j = j;
+    t.stop_at_col0 = 0;
+    t.i_min = s_lo * 64 * K;
+    t.nops0 = nops;
+    t.trace = (const uint32_t*)ctx->trace.p;
+    t.sw_best = (const int*)ctx->small.p;
+    t.sw_pos = (const unsigned long long*)((char*)ctx->small.p + 8);
+    t.ops = (uint8_t*)ctx->ops.p;
+    t.hdr = d_hdr;
+    hipLaunchKernelGGL(traceback_walk, dim3(1), dim3(64), 0, st, t);
+    HIPCK(ctx, hipGetLastError());
+    long long h_hdr[5] = {0, 0, 0, 0, 0};
+    int h_err = 0;
+    HIPCK(ctx, hipMemcpyAsync(h_hdr, d_hdr, sizeof h_hdr, hipMemcpyDeviceToHost, st));
+    HIPCK(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
+    HIPCK(ctx, hipStreamSynchronize(st));
+    if (h_err) return fail(ctx, SA_ERR_HIP, "persistent fill (band %d..%d): a bounded wait expired (results discarded)", s_lo, s_hi);
+    nops = h_hdr[0];
+    const int ni = (int)h_hdr[3], nj = (int)h_hdr[4];
+    const bool handover = ni == t.i_min && ni > 0 && nj > 0 && ni < i;
+    i = ni;
+    j = nj;
+    if (!handover) break;
+  }
+  if (nops > 0) {
+    out->ops = (uint8_t*)malloc((size_t)nops);
+    if (!out->ops) return fail(ctx, SA_ERR_NOMEM, "host malloc of %lld ops failed", nops);
+    HIPCK(ctx, hipMemcpyAsync(out->ops, ctx->ops.p, (size_t)nops, hipMemcpyDeviceToHost, st));
+  }
+  HIPCK(ctx, hipEventRecord(ctx->ev[3], st));
+  HIPCK(ctx, hipEventSynchronize(ctx->ev[3]));
+  out->n_ops = nops;
+  out->start_i = i;
+  out->start_j = j;
   return SA_OK;
 }
 
 // Traceback over the codes of the last fill + D2H of score / end cell / op list.  Synchronises.
 int traceback_impl(sa_ctx* ctx, int start_i, int start_j, bool want_tb, sa_result* out) {
+  if (ctx->last.ckpt && want_tb) return traceback_ckpt(ctx, start_i, start_j, out);
   hipStream_t st = ctx->stream;
   const int kind = ctx->last.kind, m = ctx->last.m, n = ctx->last.n;
   int* d_score = (int*)ctx->small.p;
@@ -1074,6 +1213,12 @@ int sa_set_option(sa_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return SA_ERR_ARG;
   if (!strcmp(name, "persistent")) {
     c->persist = value != 0;
+  } else if (!strcmp(name, "checkpoint_band")) {  // 0: checkpoint only when the codes do not fit
+    if (value < 0) return fail(c, SA_ERR_ARG, "checkpoint_band must be >= 0");
+    c->force_band = (int)value;
+  } else if (!strcmp(name, "trace_budget_mb")) {  // 0: automatic
+    if (value < 0) return fail(c, SA_ERR_ARG, "trace_budget_mb must be >= 0");
+    c->trace_budget = (size_t)value << 20;
   } else if (!strcmp(name, "batch_trace_budget_mb")) {
     if (value < 1) return fail(c, SA_ERR_ARG, "batch_trace_budget_mb must be positive");
     c->batch_trace_budget = (size_t)value << 20;

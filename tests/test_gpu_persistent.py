@@ -72,3 +72,45 @@ def test_persistent_equals_launch_path_at_100k(engine):
         assert (sa_.score, sa_.end, sa_.start) == (sb.score, sb.end, sb.start) and np.array_equal(sa_.ops, sb.ops)
     finally:
         engine.set_option("persistent", 1)
+
+
+def test_checkpointed_traceback_equals_oracle(engine, oracle):
+    """codes that do not fit are replaced by per-strip checkpoints and the traceback
+    recomputes `checkpoint_band` strips at a time; results are identical."""
+    import numpy as np
+
+    from conftest import DNA, PROT20, mutate, rand_seq
+
+    rng = np.random.default_rng(77)
+    try:
+        for (m, K, band) in [(700, 1, 1), (3000, 2, 3), (5000, 4, 2), (2600, 8, 1), (4000, 1, 7), (3000, 2, 1000)]:
+            x = rand_seq(rng, m, DNA)
+            y = mutate(rng, x, DNA)
+            engine.set_tuning(K, 0)
+            engine.set_option("checkpoint_band", band)
+            for kind in ("nw", "lcs", "sw"):
+                want = oracle.lcs(x, y) if kind == "lcs" else getattr(oracle, kind)(x, y, "dna")
+                got = engine.lcs(x, y) if kind == "lcs" else getattr(engine, kind)(x, y, "dna")
+                assert got.score == want.score and tuple(got.end) == tuple(want.end) and tuple(got.start) == tuple(want.start), (kind, m, K, band)
+                assert np.array_equal(got.ops, want.ops), (kind, m, K, band)
+                assert got.n_launches >= 2
+        # unrelated sequences (gappy path that wanders), protein, a local hit far from the corner, empty local alignment
+        engine.set_tuning(2, 0)
+        engine.set_option("checkpoint_band", 2)
+        x, y = rand_seq(rng, 2500, DNA), rand_seq(rng, 3100, DNA)
+        for kind in ("nw", "sw"):
+            want, got = getattr(oracle, kind)(x, y, "dna"), getattr(engine, kind)(x, y, "dna")
+            assert got.score == want.score and np.array_equal(got.ops, want.ops), kind
+        xp = rand_seq(rng, 1500, PROT20)
+        yp = mutate(rng, xp, PROT20, 0.2, 0.05, 0.05)
+        want, got = oracle.nw(xp, yp, "protein", -11.0, -1.0), engine.nw(xp, yp, "protein", -11.0, -1.0)
+        assert got.score == want.score and np.array_equal(got.ops, want.ops)
+        core = rand_seq(rng, 300, DNA)
+        xl, yl = rand_seq(rng, 900, DNA) + core + rand_seq(rng, 1400, DNA), rand_seq(rng, 200, DNA) + core + rand_seq(rng, 2000, DNA)
+        want, got = oracle.sw(xl, yl, "dna"), engine.sw(xl, yl, "dna")
+        assert (got.score, tuple(got.end), tuple(got.start)) == (want.score, tuple(want.end), tuple(want.start)) and np.array_equal(got.ops, want.ops)
+        got = engine.sw("A" * 700, "C" * 900, "dna")
+        assert got.score == 0 and len(got.ops) == 0
+    finally:
+        engine.set_option("checkpoint_band", 0)
+        engine.set_tuning(0, 0)
