@@ -283,7 +283,9 @@ def main():
                 "rows_per_lane": res.rows_per_lane,
                 "tile_steps": res.tile_steps,
                 "parallelism": "single GPU" if world == 1 else f"column stripes x{world}",
-                "schedule": "persistent strip pipeline" if res.n_launches == 1 else "one launch per tile diagonal",
+                "schedule": ("persistent strip pipeline" if res.n_launches == 1 else
+                             f"persistent strip pipeline, checkpointed: codes recomputed in {res.n_launches - 1} bands during the traceback"
+                             if res.n_launches < 100 else "one launch per tile diagonal"),
             },
             "result": {"score": int(res.score), "n_ops": int(len(res.ops))},
             "breakdown_ms_per_step": {
@@ -300,7 +302,7 @@ def main():
                 "traffic": pmc_traffic(args, m, n, world, res),
                 "traffic_note": "HBM bytes per launch, WRITE_SIZE + 2 x FETCH_SIZE of profiles/r01_nw1m_pmc_v4_persistent.json; "
                                 "algorithmic: 0.25 B/cell trace + 16 B per strip column of bottom-row hand-off",
-                "kernel": "fill_persistent" if res.n_launches == 1 else "fill_tile",
+                "kernel": "fill_persistent" if res.n_launches < 100 else "fill_tile",
                 "ops_per_cell": ops,
                 "avg_launch_us": round(kernel_ms * 1e3 / max(launches, 1), 2),
                 "hbm": {

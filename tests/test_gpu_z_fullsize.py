@@ -52,3 +52,34 @@ def test_lcs_1mb_properties(engine, pair_1mb):
     engine.set_option("persistent", 0)
     b = engine.lcs(x, y)
     assert b.score == a.score and np.array_equal(a.ops, b.ops)
+
+
+def test_nw_1mb_checkpointed_bands_equal_one_slab(engine, pair_1mb):
+    """The same pair with the codes recomputed 300 strips at a time from per-strip checkpoints."""
+    x, y = pair_1mb
+    engine.set_option("persistent", 1)
+    a = engine.nw(x, y, "dna")
+    engine.set_option("checkpoint_band", 300)
+    try:
+        b = engine.nw(x, y, "dna")
+    finally:
+        engine.set_option("checkpoint_band", 0)
+    assert b.n_launches == 1 + 7  # 1954 strips of 512 rows: one checkpoint pass + 7 bands
+    assert b.score == a.score and np.array_equal(a.ops, b.ops)
+
+
+def test_nw_2mb_beyond_device_memory(engine, oracle):
+    """2 Mb x 2 Mb: 1 TB of codes cannot be held on one 288 GB device; the engine switches to
+    checkpoints + banded recomputation by itself.  Score and complete op list equal the banded
+    oracle's."""
+    from sequencealigner_amd.synth import dna_pair
+
+    x, y = dna_pair(2_000_000, seed=4321)
+    engine.release_workspace()
+    a = engine.nw(x, y, "dna")
+    assert a.n_launches >= 3
+    want, touched = oracle.nw_banded(x, y, 1024, "dna")
+    assert want.rc == 0 and touched == 0
+    assert a.score == want.score
+    assert len(a.ops) == len(want.ops) and np.array_equal(a.ops, want.ops)
+    engine.release_workspace()
