@@ -244,15 +244,22 @@ __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF,
   if (KIND != KIND_LCS) obF = dpp_shl1(st.passF, obF);
 }
 
+// The codes are written once and read back only by the traceback: streaming (non-temporal) stores.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int K>
 __device__ __forceinline__ void store_trace(uint32_t* dst, const uint32_t (&t)[K]) {
   if (K == 1) {
-    dst[0] = t[0];
+    __builtin_nontemporal_store(t[0], dst);
   } else if (K == 2) {
-    *reinterpret_cast<uint2*>(dst) = make_uint2(t[0], t[1]);
+    u32x2 v = {t[0], t[1]};
+    __builtin_nontemporal_store(v, reinterpret_cast<u32x2*>(dst));
   } else {
 #pragma unroll
-    for (int k = 0; k < K; k += 4) *reinterpret_cast<uint4*>(dst + k) = make_uint4(t[k], t[k + 1], t[k + 2], t[k + 3]);
+    for (int k = 0; k < K; k += 4) {
+      u32x4 v = {t[k], t[k + 1], t[k + 2], t[k + 3]};
+      __builtin_nontemporal_store(v, reinterpret_cast<u32x4*>(dst + k));
+    }
   }
 }
 
@@ -307,6 +314,8 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
 #pragma unroll
     for (int u = 0; u < 16; ++u)
       lane_step<KIND, K, BND, FLAGS>(st, ibH, ibF, yb, obH, obF, tacc, u, ldsLane, xr, a, cbase + u, dprow);
+    // (the compiler sinks the 16 x K code-packing ops of the sub-block into this branch: a score-only /
+    // checkpoint pass skips them, which is where its ~10 % come from -- not from the memory system)
     if (a.trace) store_trace<K>(tdst, tacc);
     tdst += 64 * K;
     hook(sub);
@@ -589,9 +598,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
       auto hook = [&](int sub) {
         if (sub == 0) {
           if (b > 0) {
-            // blocks 0..b-1 are complete once everything older than this sub-block's trace
+            // blocks 0..b-1 are complete once everything older than this sub-block's code
             // stores has retired (vmcnt counts loads and stores together, in issue order)
-            if (K == 8)
+            if (!a.trace)  // score-only / checkpoint pass: no code stores were issued in between
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (K == 8)
               asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else
               asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
