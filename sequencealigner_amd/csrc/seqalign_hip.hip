@@ -140,6 +140,36 @@ Tuning choose_tuning(const sa_ctx* ctx, int kind, int64_t m, int64_t n, int64_t 
   return t;
 }
 
+// Steps until the last of S strips of n columns is done when `waves` resident waves draw strips in
+// order: strip s starts when the strip above is 128 steps ahead AND a wave is free, i.e.
+// start(s) = max(128 s, start(s - waves) + n).
+double pipeline_steps(double S, double waves, double n) {
+  double start = 0;
+  for (double j = 0; j * waves <= S - 1; j += 1) start = std::max(start, 128.0 * (S - 1 - j * waves) + j * n);
+  return start + n;
+}
+
+// Rows per lane for the persistent pipeline on one GPU: the schedule above priced with the measured
+// step cost (choose_stripe_K below).  E.g. 786 432 rows: K=8 gives 1536 strips = 2 rounds with half
+// the waves idle in the second, K=4 gives 3 full rounds of cheaper steps and wins by 10 %.
+int choose_persist_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n) {
+  if (ctx->force_K) return ctx->force_K;
+  const double cell = kind == KIND_LCS ? 7.0 : (kind == KIND_SW ? 13.0 : 10.0);
+  const double waves = 4.0 * ctx->n_cu * std::max(1, ctx->wps);
+  double best = 1e300;
+  int bestK = 1;
+  for (int K : {1, 2, 4, 8}) {
+    const double step = (cell * K + 18.0) * 4.0;
+    const double S = std::ceil((double)m / (64.0 * K));
+    const double est = pipeline_steps(S, waves, (double)n + 63.0) * step;
+    if (est < best) {
+      best = est;
+      bestK = K;
+    }
+  }
+  return bestK;
+}
+
 // Rows per lane for the persistent pipeline over column stripes.  Every rank evaluates the same
 // model of the LAST stripe's finishing time and so picks the same K: its first strip can start
 // once each stripe to its left has emitted its first border chunk (T_first each), then it works
@@ -161,9 +191,7 @@ int choose_stripe_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n, int64_t n
     const double S = std::ceil((double)m / (64.0 * K));
     const double hops = n > 0 ? std::max(0.0, std::round((double)n_total / (double)n) - 1.0) : 0.0;
     const double first = ((double)n + (R > 0 ? (double)R / (64.0 * K) : 1.0) * 128.0) * step;
-    const double own = std::ceil(S / waves) * ((double)n + 63.0) * step;
-    const double ramp = std::min(S, waves) * 128.0 * step;
-    const double est = hops * first + own + ramp;
+    const double est = hops * first + pipeline_steps(S, waves, (double)n + 63.0) * step;
     if (est < best) {
       best = est;
       bestK = K;
@@ -317,14 +345,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
     tun.K = choose_stripe_K(ctx, kind, m, n, sd->n_total, ev_out ? R : 0);
     tun.C = 64;
   } else if (persist) {
-    // as many rows per lane as still leave every SIMD a strip of its own
-    tun.K = 1;
-    for (int K : {8, 4, 2})
-      if ((m + 64 * K - 1) / (64 * K) >= ctx->n_cu) {
-        tun.K = K;
-        break;
-      }
-    if (ctx->force_K) tun.K = ctx->force_K;
+    tun.K = choose_persist_K(ctx, kind, m, n);
     tun.C = 64;
   }
   const int K = tun.K, C = tun.C;
