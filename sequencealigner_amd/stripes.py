@@ -20,6 +20,7 @@ orchestration is exercised on CPU by the tests with an oracle-backed engine.
 from __future__ import annotations
 
 import contextlib
+import os
 
 import numpy as np
 
@@ -94,7 +95,7 @@ class StripedAligner:
         self.min_stripe_cols = int(min_stripe_cols)
         # overlap: persistent fill with the borders crossing on two transfer streams while it runs;
         # False: the launch-per-diagonal schedule with the transfers in line on the compute stream
-        self.overlap = bool(overlap)
+        self.overlap = bool(overlap) and os.environ.get("SA_STRIPES_OVERLAP", "1") != "0"
         # link (g-1, g) uses group g & 1: a rank's two links never share a backend queue
         self.link_groups = [None, None]
         if world > 2 and hasattr(dist, "new_group"):
