@@ -152,7 +152,8 @@ struct Lane {
 template <int KIND, int K, bool BND, int FLAGS>
 __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF, int& yb, int& obH, int& obF,
                                           uint32_t (&tacc)[K], const int u, const char* ldsLane,
-                                          const uint32_t (&xr)[K], const FillArgs& a, const int c, int* dprow) {
+                                          const uint32_t (&xr)[K], const FillArgs& a, const int c, int* dprow,
+                                          uint32_t (&sbk)[K]) {
   constexpr bool FRAC = (FLAGS & FLAG_FRAC) != 0;
   constexpr bool DUMP = (FLAGS & FLAG_DUMP) != 0;
   const int go = a.go, ge = a.ge, n = a.n;
@@ -205,13 +206,19 @@ __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF,
       int e = max(st.Hg[k], add_gap<FRAC>(st.E[k], ge, a.fe));     // tag 1
       int mv = diag + sg;                                          // tag 2
       if (KIND == KIND_SW) {
+        // E and F are floored individually because the floored values are carried forward
+        // (main.cpp:968-973); the floor of M only ever feeds the cell maximum, where the 'X' floor
+        // below (tag 3 beats every tagged value <= 2) subsumes it.
         f = max(f, 0);
         e = max(e, 1);
-        mv = max(mv, 2);
       }
       int ht = max(max(mv, e), f);
       if (KIND == KIND_SW) ht = max(ht, 3);
       tacc[k] = __builtin_amdgcn_alignbit((uint32_t)ht, tacc[k], 2);
+      // SW: pack the code here and now.  Left alone the compiler sinks all 16 x K packing ops to the
+      // end of the sub-block and keeps every cell's maximum alive until then, which for SW (row
+      // bests on top) no longer fits 256 VGPRs and turns into AGPR copies.
+      if (KIND == KIND_SW) asm volatile("" : "+v"(tacc[k]));
       h = ht & ~3;
       if (BND) {
         e = act ? e : st.E[k];
@@ -223,9 +230,13 @@ __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF,
       f_last = f;
     }
     if (KIND == KIND_SW) {
-      const bool better = BND ? (act && h > st.best[k]) : (h > st.best[k]);
-      st.best[k] = better ? h : st.best[k];
-      st.bestc[k] = better ? c : st.bestc[k];
+      // first row-major maximum (main.cpp:1124-1127), two ops per cell: inside a 16-step sub-block a
+      // row keeps max over its cells of (h << 2) + (15 - u) -- larger score first, then the earlier
+      // column; run_block folds it into (best, bestc) with a strict compare once per sub-block.
+      // h = 4 * score < 2^29 (check_scoring), so the key stays below 2^31.
+      uint32_t key = ((uint32_t)h << 2) + (uint32_t)(15 - u);
+      if (BND) key = act ? key : 0u;
+      sbk[k] = max(sbk[k], key);
     }
     if (DUMP) {
       if (act && dprow[k] >= 0) a.dp[(size_t)dprow[k] + c + 1] = (KIND == KIND_LCS) ? h : (h >> 2);
@@ -307,13 +318,22 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
   uint32_t* tdst = a.trace + (((size_t)(s - a.trace_s0) * a.W + (Tb >> 4)) * 64 + lane) * K;
 #pragma unroll kUnroll
   for (int sub = 0; sub < 4; ++sub) {
-    uint32_t tacc[K];
+    uint32_t tacc[K], sbk[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) tacc[k] = 0;
+    for (int k = 0; k < K; ++k) tacc[k] = 0, sbk[k] = 0;
     const int cbase = Tb + 16 * sub - lane;
 #pragma unroll
     for (int u = 0; u < 16; ++u)
-      lane_step<KIND, K, BND, FLAGS>(st, ibH, ibF, yb, obH, obF, tacc, u, ldsLane, xr, a, cbase + u, dprow);
+      lane_step<KIND, K, BND, FLAGS>(st, ibH, ibF, yb, obH, obF, tacc, u, ldsLane, xr, a, cbase + u, dprow, sbk);
+    if (KIND == KIND_SW) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int v = (int)(sbk[k] >> 4) << 2;  // the 4 * score of the sub-block's best cell in this row
+        const bool better = v > st.best[k];     // strict: earlier sub-blocks hold the smaller columns
+        st.best[k] = better ? v : st.best[k];
+        st.bestc[k] = better ? cbase + 15 - (int)(sbk[k] & 15u) : st.bestc[k];
+      }
+    }
     // (the compiler sinks the 16 x K code-packing ops of the sub-block into this branch: a score-only /
     // checkpoint pass skips them, which is where its ~10 % come from -- not from the memory system)
     if (a.trace) store_trace<K>(tdst, tacc);

@@ -758,6 +758,18 @@ void border_chains(int kind, int64_t m, int64_t n, const sa_scoring* sc, std::ve
   rowb.assign((size_t)n + 1, 0);
   colb.assign((size_t)m + 1, 0);
   if (kind != KIND_NW) return;
+  if (sc->gap_open == std::floor(sc->gap_open) && sc->gap_extend == std::floor(sc->gap_extend) && std::fabs(sc->gap_open) < 1e6 &&
+      std::fabs(sc->gap_extend) < 1e6) {
+    // integral penalties: the same two chains in int arithmetic (exact: no truncation happens)
+    const int go = (int)sc->gap_open, ge = (int)sc->gap_extend;
+    for (int64_t j = 1; j <= n; ++j) rowb[j] = (j == 1) ? go : rowb[j - 1] + ge;
+    int fprev = kNeg;
+    for (int64_t i = 1; i <= m; ++i) {
+      fprev = std::max(colb[i - 1] + go, fprev + ge);
+      colb[i] = fprev;
+    }
+    return;
+  }
   for (int64_t j = 1; j <= n; ++j) rowb[j] = (j == 1) ? add_gap(rowb[0], sc->gap_open) : add_gap(rowb[j - 1], sc->gap_extend);
   int fprev = kNeg;
   for (int64_t i = 1; i <= m; ++i) {
