@@ -795,7 +795,14 @@ __device__ __forceinline__ uint32_t window_code(const TraceWindow& w, int q, boo
 // the window path needs 64 rows above and room for 16 columns of drift on both sides
 __device__ __forceinline__ bool window_ok(int i, int j) { return i >= 64 && j >= 81; }
 
+constexpr int kTraceStage = 32768;  // bytes of moves staged in LDS between flushes
+
 __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
+  // The moves are staged in LDS and written out in bulk: with no global stores inside the walk, the
+  // only vector-memory operations in flight are the loads of the NEXT window, so waiting for them
+  // at the top of the next round (vmcnt counts loads and stores together, in order) waits for
+  // nothing else -- the prefetch really overlaps the walk through the current window.
+  __shared__ uint8_t stage[kTraceStage];
   const int d = threadIdx.x;
   const bool tagged = a.kind != KIND_LCS;
   int lgK = 0;
@@ -817,34 +824,44 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
     a.hdr[1] = i;
     a.hdr[2] = j;
   }
-  long long nops = a.nops0;
+  long long nops = a.nops0;     // moves emitted so far
+  long long flushed = a.nops0;  // ... of which ops[0, flushed) have reached global memory
   const int i_min = a.i_min;
-  uint32_t warm = 0;
-  bool have_next = false;  // nw holds the window of entry cell (pi, pj)
+  auto flush = [&]() {
+    wave_lds_fence();  // the staged bytes were written by other lanes
+    const int cnt = (int)(nops - flushed);
+    for (int q = d; q < cnt; q += 64) a.ops[flushed + q] = stage[q];
+    flushed = nops;
+    wave_lds_fence();  // later staging writes stay behind these reads
+  };
+  bool have = false;  // nw holds the window of entry cell (pi, pj)
   int pi = 0, pj = 0;
   TraceWindow nw{0, 0, 0, 0};
   bool stopped = false;
   while (i > i_min && j > 0 && !stopped) {
+    if (nops - flushed > kTraceStage - 192) flush();
+    const int sbase = (int)(nops - flushed);
     if (window_ok(i - i_min, j)) {
       // ---- fast path: 64 rows per memory round trip, the next window already in flight ----
-      TraceWindow w;
-      int j0, o;
-      if (have_next && pi == i && abs(j - pj) <= 14) {
-        w = nw;
-        j0 = pj;
-        o = j - pj;
-      } else {
-        w = load_trace_window(a.trace, i - i_min, j, d, lgK, a.W);
-        j0 = j;
-        o = 0;
+      if (!(have && pi == i && abs(j - pj) <= 14)) {
+        // no usable prediction: fetch the window of this very cell and come round again
+        pi = i;
+        pj = j;
+        have = true;
+        nw = load_trace_window(a.trace, pi - i_min, pj, d, lgK, a.W);
+        continue;
       }
-      have_next = window_ok(i - 64 - i_min, j - 64);
-      if (have_next) {
+      const TraceWindow w = nw;
+      const int j0 = pj;
+      int o = j - pj;
+      // prefetch along the diagonal; a path that drifts more than 14 columns in 64 rows misses it
+      have = window_ok(i - 64 - i_min, j - 64);
+      if (have) {
         pi = i - 64;
         pj = j - 64;
         nw = load_trace_window(a.trace, pi - i_min, pj, d, lgK, a.W);
       }
-      int dcur = 0;
+      int dcur = 0, emitted = 0;
       const int o_in = o;
       while (dcur < 64) {
         const uint32_t cM = window_code(w, w.pb + o, tagged);
@@ -864,23 +881,24 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
           L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);
         }
         if (c0 == 1u) {
-          if (d == 0) a.ops[nops] = 1;
+          if (d == 0) stage[sbase + emitted] = 1;
           o -= 1;
         } else {
-          if (d >= dcur && d < dcur + L) a.ops[nops + (d - dcur)] = (uint8_t)c0;
+          if (d >= dcur && d < dcur + L) stage[sbase + emitted + (d - dcur)] = (uint8_t)c0;
           dcur += L;
           if (c0 == 2u) o += L;
         }
-        nops += L;
+        emitted += L;
+        if (emitted > 160) break;  // staging room of one round (only long runs of left moves get here)
       }
-      if (dcur == 0 && o == o_in && !stopped) {
-        have_next = false;  // no progress possible from this window (cannot happen with |o| <= 14)
-      }
+      nops += emitted;
+      if (dcur == 0 && o == o_in && !stopped) have = false;  // out of the window at once: take the generic path below
       i -= dcur;
       j = j0 - dcur + o;
       if (dcur != 0 || o != o_in || stopped) continue;
     }
     // ---- generic path (borders, SW tails, tiny matrices): one run per memory round trip ----
+    have = false;
     const bool vM = (i - d > i_min) && (j - d >= 1);
     const bool vE = (j - d >= 1);
     const bool vF = (i - d > i_min);
@@ -897,7 +915,7 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
     else
       run = __ballot(cF == 2u);
     const int L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);
-    if (d < L) a.ops[nops + d] = (uint8_t)c0;
+    if (d < L) stage[sbase + d] = (uint8_t)c0;
     nops += L;
     if (c0 != 1u) i -= L;
     if (c0 != 2u) j -= L;
@@ -906,13 +924,13 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
     if (c0 == 0u && L < 64) {
       const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)cM, L);
       if (cn == 1u || cn == 2u) {
-        if (d == 0) a.ops[nops] = (uint8_t)cn;
+        if (d == 0) stage[sbase + L] = (uint8_t)cn;
         nops += 1;
         if (cn == 1u) --j; else --i;
       }
     }
   }
-  if (warm == 0xffffffffu) a.hdr[7] = warm;  // keeps the warming loads alive; never true (codes are < 4)
+  flush();
   if (i > 0 && j > 0) {
     // NW / LCS: the walk reached the top row of a recomputed band; the host continues with the band
     // above from (i, j).  SW: it stopped at its 'X' cell.
