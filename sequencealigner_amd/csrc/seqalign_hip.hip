@@ -88,6 +88,7 @@ int ensure(sa_ctx* ctx, Buf& b, size_t bytes) {
   size_t want = (bytes + 255) & ~size_t(255);
   hipError_t e = hipMalloc(&b.p, want);
   if (e != hipSuccess) {
+    (void)hipGetLastError();
     b.p = nullptr;
     return fail(ctx, SA_ERR_NOMEM, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
   }
@@ -387,6 +388,18 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
     if (ck_bytes + strip_trace_bytes > budget) return fail(ctx, SA_ERR_NOMEM, "checkpoint rows (%.1f GB) do not fit the budget", ck_bytes / 1e9);
     band = (int)std::max<size_t>(1, std::min<size_t>((size_t)S, (budget - ck_bytes) / strip_trace_bytes));
     if (ctx->force_band > 0) band = std::min(band, ctx->force_band);
+  }
+  // The big cached workspaces of an earlier, differently shaped call may be in the way (the code slab
+  // of a 1 Mb x 1 Mb pair is 250 GB, the checkpoint rows of a 2 Mb x 2 Mb pair 62 GB): if any of them
+  // has to grow, let all of them go first so that the new sizes are what has to fit.
+  {
+    const size_t need_bot = (size_t)2 * ring * NP * 4, need_trace = no_tb ? 0 : (size_t)band * strip_trace_bytes;
+    const size_t need_dp = dump ? ((size_t)m + 1) * ((size_t)n + 1) * 4 : 0;
+    if (need_bot > ctx->bot.cap || need_trace > ctx->trace.cap || need_dp > ctx->dpbuf.cap) {
+      release(ctx->bot);
+      release(ctx->trace);
+      release(ctx->dpbuf);
+    }
   }
   if ((rc = ensure(ctx, ctx->bot, (size_t)2 * ring * NP * 4))) return rc;
   if ((rc = ensure(ctx, ctx->state, (size_t)S * NF * 64 * 4))) return rc;
