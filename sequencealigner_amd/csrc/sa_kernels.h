@@ -198,6 +198,10 @@ __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF,
       h = eq ? diag + 1 : max(up, left);
       const int code = eq ? 0 : (up >= left ? 2 : 1);
       tacc[k] |= (uint32_t)code << (2 * u);
+      // pack here and now: left alone the compiler postpones the packing of the whole sub-block and
+      // keeps both compare masks of every cell alive in SGPR pairs -- far more than there are, so
+      // they get spilled to VGPR lanes (2.5 v_readlane / v_writelane per cell before this line)
+      asm volatile("" : "+v"(tacc[k]));
       if (BND) h = act ? h : left;
     } else {
       // tagged candidates: see the header of this file
