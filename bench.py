@@ -69,6 +69,42 @@ def cpu_baseline(x, y, kind, sample):
     }, r
 
 
+def reference_baseline(x, y, kind, sample):
+    """The reference itself: oracle/_ref/aligner_ref is the UNMODIFIED /root/reference/src/main.cpp
+    compiled in the build container (oracle/Makefile `ref`); it travels to the GPU box with the tree.
+    One process = one core, which is the reference's real parallelism for one pair.  The number is
+    its own time_ms (main.cpp:736 -> :820: fill + traceback, no file I/O).  None if it cannot run here."""
+    import json as _json
+    import shutil
+    import tempfile
+
+    from oracle import pyoracle
+
+    if kind == "lcs" or pyoracle.ref_binary() is None:  # lcs writes no stats file
+        return None
+    tmp = tempfile.mkdtemp(prefix="sa_ref_")
+    try:
+        q, t = Path(tmp) / "q.fa", Path(tmp) / "t.fa"
+        q.write_bytes(b">q\n" + bytes(x[:sample]) + b"\n")
+        t.write_bytes(b">t\n" + bytes(y[:sample]) + b"\n")
+        rc, _out, _err, files, outdir = pyoracle.run_reference(q, t, 1 if kind == "nw" else 2, "dna")
+        shutil.rmtree(outdir, ignore_errors=True)
+        name = "global_stats.json" if kind == "nw" else "local_stats.json"
+        if rc != 0 or name not in files:
+            return None
+        st = _json.loads(files[name])
+        ms = float(st["time_ms"])
+        if ms <= 0:
+            return None
+        return {"value": round(sample * sample / (ms / 1e3) / 1e9, 4), "unit": "GCUPS", "cores": 1, "kind": "reference",
+                "sample": f"the compiled reference (oracle/_ref/aligner_ref, unmodified main.cpp, -O3) on the first {sample}x{sample} "
+                          f"residues of the same pair: its own time_ms = {ms:.0f} ms, score {st['score']}"}
+    except Exception:  # noqa: BLE001 -- any failure: fall back to the port
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def bench_batch(args, rank, local_rank, world, dist, torch):
     """Config 5: independent protein pairs (300-1000 aa, BLOSUM62, -5/-1), SW score + end cell
     (--workload batch) or full local alignments (--workload batch-align: + direction codes, per-pair
@@ -324,6 +360,10 @@ def main():
             line["config"]["schedule_note"] = schedule_note
         if not args.no_cpu and world == 1:
             cb, _ = cpu_baseline(x, y, args.kind, min(args.cpu_sample, m, n))
+            rb = reference_baseline(x, y, args.kind, min(args.cpu_sample // 2, m, n))
+            if rb is not None:  # the reference itself when its binary is here, the port beside it
+                rb["port"] = {"value": cb["value"], "sample": cb["sample"]}
+                cb = rb
             line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
     if dist is not None:
