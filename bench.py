@@ -219,6 +219,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample", type=int, default=40000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--unrelated", action="store_true",
+                    help="SURVEY 8d config 3 variant: independent uniform y (seed 5678) instead of the ~90 %% identity pair")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -241,7 +243,7 @@ def main():
     if args.workload in ("batch", "batch-align"):
         return bench_batch(args, rank, local_rank, world, dist, torch)
 
-    x, y = dna_pair(args.size, seed=1234)
+    x, y = dna_pair(args.size, seed=5678, related=False) if args.unrelated else dna_pair(args.size, seed=1234)
     m, n = len(x), len(y)
     cells = m * n
 
@@ -316,7 +318,7 @@ def main():
             "dtype": "int32",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.kind.upper()} {m}x{n} synthetic DNA (~90% identity, seed 1234), EDNAFULL, gaps -5/-1, "
+                "workload": f"{args.kind.upper()} {m}x{n} synthetic DNA ({'unrelated, seed 5678' if args.unrelated else '~90% identity, seed 1234'}), EDNAFULL, gaps -5/-1, "
                             f"score + full traceback, bit-exact op list",
                 "rows_per_lane": res.rows_per_lane,
                 "tile_steps": res.tile_steps,

@@ -867,33 +867,50 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
       }
       int dcur = 0, emitted = 0;
       const int o_in = o;
+      // The lane's 32 codes around its own cell of the entry diagonal, as one 64-bit value: the code
+      // at drift o (-16..15) is bits [2(o+16), 2(o+16)+1].  Two funnel shifts per window; every step
+      // of the walk is then a 64-bit shift and a compare.
+      const int sh0 = 2 * (w.pb - 16);
+      const unsigned long long F = ((unsigned long long)__builtin_amdgcn_alignbit(w.w2, w.w1, sh0) << 32) |
+                                   (unsigned long long)__builtin_amdgcn_alignbit(w.w1, w.w0, sh0);
+      // raw codes: NW / SW store the winner's tag (M 2, E 1, F 0, SW zero cell 3), LCS the op itself
+      const uint32_t rawD = tagged ? 2u : 0u, rawU = tagged ? 0u : 2u;
       while (dcur < 64) {
-        const uint32_t cM = window_code(w, w.pb + o, tagged);
-        const uint32_t c0 = (uint32_t)__builtin_amdgcn_readlane((int)cM, dcur);
-        if (c0 == 4u) break;  // drifted out of the window: re-centre
-        if (c0 == 3u) {       // SW stop cell
+        if (o < -16 || o > 15) break;  // drifted out of the window: re-centre
+        const uint32_t rM = (uint32_t)(F >> (2 * (o + 16))) & 3u;  // the lane's cell on the current diagonal
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)rM, dcur);
+        if (tagged && r0 == 3u) {  // SW stop cell
           stopped = true;
           break;
         }
-        int L = 1;
-        if (c0 == 0u) {
-          const unsigned long long run = __ballot(cM == 0u) >> dcur;
+        int L;
+        if (r0 == rawD) {  // diagonal run: rows dcur.. whose cell on this diagonal is a diagonal move
+          const unsigned long long run = __ballot(rM == rawD) >> dcur;
           L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);
-        } else if (c0 == 2u) {
-          const uint32_t cF = window_code(w, w.pb + o + (d - dcur), tagged);
-          const unsigned long long run = __ballot(cF == 2u) >> dcur;
-          L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);
-        }
-        if (c0 == 1u) {
-          if (d == 0) stage[sbase + emitted] = 1;
-          o -= 1;
-        } else {
-          if (d >= dcur && d < dcur + L) stage[sbase + emitted + (d - dcur)] = (uint8_t)c0;
+          if (d >= dcur && d < dcur + L) stage[sbase + emitted + (d - dcur)] = 0;
           dcur += L;
-          if (c0 == 2u) o += L;
+        } else if (r0 == rawU) {  // up run: row dcur + k is entered at drift o + k
+          const int ol = o + (d - dcur);
+          const bool in = d >= dcur && ol <= 15;
+          const uint32_t rF = (uint32_t)(F >> (2 * ((in ? ol : 0) + 16))) & 3u;
+          const unsigned long long run = __ballot(in && rF == rawU) >> dcur;
+          L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);
+          if (d >= dcur && d < dcur + L) stage[sbase + emitted + (d - dcur)] = 2;
+          dcur += L;
+          o += L;
+        } else {  // left run inside row dcur: lane k looks k cells to the left
+          const unsigned long long Fd = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(F >> 32), dcur) << 32) |
+                                        (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)F, dcur);
+          const int ol = o - d;
+          const bool in = ol >= -16;
+          const uint32_t rL = (uint32_t)(Fd >> (2 * ((in ? ol : 0) + 16))) & 3u;
+          const unsigned long long run = __ballot(in && rL == 1u);
+          L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);
+          if (d < L) stage[sbase + emitted + d] = 1;
+          o -= L;
         }
         emitted += L;
-        if (emitted > 160) break;  // staging room of one round (only long runs of left moves get here)
+        if (emitted > 128) break;  // staging room of one round
       }
       nops += emitted;
       if (dcur == 0 && o == o_in && !stopped) have = false;  // out of the window at once: take the generic path below
