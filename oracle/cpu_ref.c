@@ -83,7 +83,17 @@ static void init_maps(void) {
   for (int i = 0; p[i]; ++i) g_prot_idx[(unsigned char)p[i]] = (unsigned char)i;
 }
 
+/* mode ORC_MODE_CUSTOM: a caller-supplied 256 x 256 table (INT16_MIN = invalid pair), used by the
+ * tests of other scoring schemes (the seed_aligner's tables, main_fmindex.cpp:25-100) */
+static int16_t g_custom[256 * 256];
+void orc_set_custom_table(const int16_t* t) { memcpy(g_custom, t, sizeof g_custom); }
+
 int orc_sigma(int mode, unsigned char x, unsigned char y, int* ok) {
+  if (mode == ORC_MODE_CUSTOM) {
+    const int16_t v = g_custom[(unsigned)x * 256u + y];
+    *ok = v != INT16_MIN;
+    return *ok ? v : 0;
+  }
   pthread_once(&g_once, init_maps);
   const unsigned char* map = mode == ORC_MODE_DNA ? g_dna_idx : g_prot_idx;
   unsigned ix = map[x], iy = map[y];

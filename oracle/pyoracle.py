@@ -17,7 +17,7 @@ _HERE = Path(__file__).resolve().parent
 _LIB = _HERE / "_build" / "libcpu_ref.so"
 _REF = _HERE / "_ref" / "aligner_ref"
 
-MODE = {"dna": 0, "protein": 1}
+MODE = {"dna": 0, "protein": 1, "custom": 2}
 
 
 class _Res(C.Structure):
@@ -110,6 +110,14 @@ class Oracle:
                 out.ptr = np.frombuffer(C.string_at(r.ptr, (m + 1) * (n + 1)), dtype="S1").reshape(m + 1, n + 1).copy()
         self.lib.orc_free(C.byref(r))
         return out
+
+    def set_custom_table(self, scores: dict):
+        """scores: {"xy": value} for every valid residue pair; selects mode "custom" for later calls"""
+        t = np.full((256, 256), np.iinfo(np.int16).min, np.int16)
+        for pair, v in scores.items():
+            t[ord(pair[0]), ord(pair[1])] = v
+        self.lib.orc_set_custom_table.argtypes = [C.c_void_p]
+        self.lib.orc_set_custom_table(t.ctypes.data)
 
     def sigma(self, mode, x, y):
         ok = C.c_int(0)

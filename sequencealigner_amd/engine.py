@@ -293,7 +293,7 @@ class Engine:
             raise self._err(rc, r)
         return self._wrap(r, 0, 0, False)
 
-    def sw_batch(self, seqs, off_x, len_x, off_y, len_y, mode="protein", gap_open=-5.0, gap_extend=-1.0):
+    def sw_batch(self, seqs, off_x, len_x, off_y, len_y, mode="protein", gap_open=-5.0, gap_extend=-1.0, sub=None, idx256=None):
         seqs = _u8(seqs)
         off_x = np.ascontiguousarray(off_x, np.int64)
         off_y = np.ascontiguousarray(off_y, np.int64)
@@ -303,7 +303,7 @@ class Engine:
         score = np.zeros(n, np.int32)
         ei = np.zeros(n, np.int32)
         ej = np.zeros(n, np.int32)
-        sc, keep = self._scoring(mode, gap_open, gap_extend)
+        sc, keep = self._scoring(mode, gap_open, gap_extend, sub, idx256)
         ms = C.c_float(0)
         rc = self.lib.sa_sw_batch(self.ctx, seqs.ctypes.data, off_x.ctypes.data, len_x.ctypes.data, off_y.ctypes.data,
                                   len_y.ctypes.data, n, C.byref(sc), score.ctypes.data, ei.ctypes.data, ej.ctypes.data,
