@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/seqalign_hip.h"
@@ -944,6 +945,50 @@ void launch_batch_k(int K, hipStream_t st, int count, int alpha, const BatchArgs
   }
 }
 
+// Host op pools of sa_sw_batch_align: page-locked (the 1.3 GB of moves of a million pairs come back at
+// link speed instead of through the pageable-copy staging) and recycled -- sa_free_pool parks one
+// buffer here and the next call takes it back if it is large enough, so a serving loop pins once.
+struct PoolCache {
+  std::mutex mu;
+  void* p = nullptr;
+  size_t cap = 0;
+} g_pool_cache;
+
+uint8_t* pool_acquire(size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lk(g_pool_cache.mu);
+    if (g_pool_cache.p && g_pool_cache.cap >= bytes) {
+      void* p = g_pool_cache.p;
+      g_pool_cache.p = nullptr;
+      return (uint8_t*)p;
+    }
+  }
+  void* p = nullptr;
+  // 16 bytes in front remember the capacity for pool_release
+  if (hipHostMalloc(&p, bytes + 16, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  *(size_t*)p = bytes;
+  return (uint8_t*)p + 16;
+}
+
+void pool_release(uint8_t* pool) {
+  if (!pool) return;
+  void* base = pool - 16;
+  const size_t cap = *(size_t*)base;
+  void* drop = base;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_cache.mu);
+    if (!g_pool_cache.p || g_pool_cache.cap < cap) {
+      drop = g_pool_cache.p ? (char*)g_pool_cache.p - 16 : nullptr;
+      g_pool_cache.p = pool;
+      g_pool_cache.cap = cap;
+    }
+  }
+  if (drop) (void)hipHostFree(drop);
+}
+
 // Outputs of the aligning variant (sa_sw_batch_align): per pair the 'X' cell and the op list.
 struct BatchAlign {
   int32_t* start_i;
@@ -992,7 +1037,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
       al->start_i[k] = al->start_j[k] = 0;
       pool_total += ((int64_t)len_x[k] + len_y[k] + 3) & ~3LL;
     }
-    *al->pool = (uint8_t*)malloc((size_t)std::max<int64_t>(pool_total, 4));
+    *al->pool = pool_acquire((size_t)std::max<int64_t>(pool_total, 4));
     if (!*al->pool) return fail(ctx, SA_ERR_NOMEM, "host malloc of the %lld-byte op pool failed", (long long)pool_total);
     if (al->pool_bytes) *al->pool_bytes = pool_total;
   }
@@ -1001,7 +1046,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     bool keep = false;
     ~PoolGuard() {
       if (al && !keep && *al->pool) {
-        free(*al->pool);
+        pool_release(*al->pool);
         *al->pool = nullptr;
       }
     }
@@ -1340,6 +1385,6 @@ int sa_sw_batch_align(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, co
   return run_batch(ctx, seqs, off_x, len_x, off_y, len_y, n_pairs, sc, score, end_i, end_j, kernel_ms, &al);
 }
 
-void sa_free_pool(uint8_t* pool) { free(pool); }
+void sa_free_pool(uint8_t* pool) { pool_release(pool); }
 
 }  // extern "C"
