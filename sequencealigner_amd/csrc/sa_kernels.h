@@ -194,14 +194,16 @@ __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF,
     const int left = st.H[k];
     int h;
     if (KIND == KIND_LCS) {
+      // Tagged like NW: registers hold 4 * L + 1 (the value as a LEFT candidate, tag 1); the cell above
+      // becomes the UP candidate with + 1 (tag 2) and the diagonal one, on a match, 4 * (L_diag + 1) + 3.
+      // A match always wins (L_diag + 1 >= L_up, L_left), a tie between up and left goes to up
+      // (main.cpp:1581), so one max3 yields value and direction: 7 ops per cell, no compare masks.
       const bool eq = (xr[k] == (uint32_t)yv);
-      h = eq ? diag + 1 : max(up, left);
-      const int code = eq ? 0 : (up >= left ? 2 : 1);
-      tacc[k] |= (uint32_t)code << (2 * u);
-      // pack here and now: left alone the compiler postpones the packing of the whole sub-block and
-      // keeps both compare masks of every cell alive in SGPR pairs -- far more than there are, so
-      // they get spilled to VGPR lanes (2.5 v_readlane / v_writelane per cell before this line)
-      asm volatile("" : "+v"(tacc[k]));
+      const int dc = eq ? diag + 6 : 0;
+      const int ht = max(max(dc, up + 1), left);
+      tacc[k] = __builtin_amdgcn_alignbit((uint32_t)ht, tacc[k], 2);
+      // one v_and_or_b32; written as C the compiler splits it into an AND and two ORs per cell
+      asm("v_and_or_b32 %0, %1, -4, 1" : "=v"(h) : "v"(ht));
       if (BND) h = act ? h : left;
     } else {
       // tagged candidates: see the header of this file
@@ -243,7 +245,7 @@ __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF,
       sbk[k] = max(sbk[k], key);
     }
     if (DUMP) {
-      if (act && dprow[k] >= 0) a.dp[(size_t)dprow[k] + c + 1] = (KIND == KIND_LCS) ? h : (h >> 2);
+      if (act && dprow[k] >= 0) a.dp[(size_t)dprow[k] + c + 1] = h >> 2;
     }
     diag = left;
     st.H[k] = h;
@@ -358,27 +360,28 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
 // coh: the border arrived from another GPU while this kernel was running (sc1 loads)
 template <int KIND, int K, int FLAGS>
 __device__ __forceinline__ void strip_begin(Lane<KIND, K>& st, const FillArgs& a, const int r0, const bool coh = false) {
-  constexpr int SH = (KIND == KIND_LCS) ? 0 : 2;
+  constexpr int SH = 2;
+  constexpr int TAG = (KIND == KIND_LCS) ? 1 : 0;  // LCS registers carry the left-candidate tag
   const int* lbi = reinterpret_cast<const int*>(a.lb);
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int row = min(r0 + k + 1, a.m);
     const int2 b = coh ? make_int2(ld_coherent(lbi + 2 * row), ld_coherent(lbi + 2 * row + 1)) : a.lb[row];
-    st.H[k] = b.x * (1 << SH);
-    st.E[k] = (KIND == KIND_LCS) ? b.y : b.y * (1 << SH) + 1;
+    st.H[k] = b.x * (1 << SH) + TAG;
+    st.E[k] = (KIND == KIND_LCS) ? 0 : b.y * (1 << SH) + 1;
     st.best[k] = 0;
     st.bestc[k] = -1;
   }
   st.passH = st.H[K - 1];
   st.passF = (KIND == KIND_NW) ? kNeg : 0;
   st.ypass = 0;
-  st.dprev = (coh ? ld_coherent(lbi + 2 * min(r0, a.m)) : a.lb[min(r0, a.m)].x) * (1 << SH);
+  st.dprev = (coh ? ld_coherent(lbi + 2 * min(r0, a.m)) : a.lb[min(r0, a.m)].x) * (1 << SH) + TAG;
 }
 
 // outputs of a finished strip: right border (column stripes), SW row bests, the final score
 template <int KIND, int K>
 __device__ __forceinline__ void strip_end(const Lane<KIND, K>& st, const FillArgs& a, const int s, const int rowg, const int r0) {
-  constexpr int SH = (KIND == KIND_LCS) ? 0 : 2;
+  constexpr int SH = 2;
   if (a.rb) {  // the lane's rows froze at the stripe's last column
 #pragma unroll
     for (int k = 0; k < K; ++k)
@@ -758,8 +761,8 @@ __device__ __forceinline__ uint32_t trace_code(const uint32_t* __restrict__ trac
   const int t = c + l;
   const size_t idx = ((((size_t)s * W + (t >> 4)) * 64 + l) << lgK) + k;
   const uint32_t raw = (trace[idx] >> (2 * (t & 15))) & 3u;
-  // NW / SW cells store the winner's tag (M 2, E 1, F 0, SW zero cell 3); LCS stores the op itself
-  return tagged ? (raw == 3u ? 3u : 2u - raw) : raw;
+  // NW / SW cells store the winner's tag (M 2, E 1, F 0, SW zero cell 3); LCS: diagonal 3, up 2, left 1
+  return tagged ? (raw == 3u ? 3u : 2u - raw) : (raw == 3u ? 0u : raw);
 }
 
 // A 64-row window of codes held in registers: lane d keeps three consecutive trace dwords (48
@@ -873,8 +876,8 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
       const int sh0 = 2 * (w.pb - 16);
       const unsigned long long F = ((unsigned long long)__builtin_amdgcn_alignbit(w.w2, w.w1, sh0) << 32) |
                                    (unsigned long long)__builtin_amdgcn_alignbit(w.w1, w.w0, sh0);
-      // raw codes: NW / SW store the winner's tag (M 2, E 1, F 0, SW zero cell 3), LCS the op itself
-      const uint32_t rawD = tagged ? 2u : 0u, rawU = tagged ? 0u : 2u;
+      // raw codes: NW / SW store the winner's tag (M 2, E 1, F 0, SW zero cell 3), LCS diagonal 3, up 2, left 1
+      const uint32_t rawD = tagged ? 2u : 3u, rawU = tagged ? 0u : 2u;
       while (dcur < 64) {
         if (o < -16 || o > 15) break;  // drifted out of the window: re-centre
         const uint32_t rM = (uint32_t)(F >> (2 * (o + 16))) & 3u;  // the lane's cell on the current diagonal

@@ -457,7 +457,12 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   // written by its strip before the strip below reads it.
   int* row0H = botH + (size_t)(ring - 1) * NP;
   int* row0F = botF + (size_t)(ring - 1) * NP;
-  if (ring == 2) {
+  if (kind == KIND_LCS) {  // LCS registers hold 4 * L + 1 (sa_kernels.h): row 0 of the matrix is all ones
+    if (ring == 2)
+      HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)botH, 1, (size_t)2 * NP, st));
+    else
+      HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)row0H, 1, (size_t)NP, st));
+  } else if (ring == 2) {
     HIPCK(ctx, hipMemsetAsync(botH, 0, (size_t)2 * NP * 4, st));
     HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)botF, kind == KIND_NW ? kNeg : 0, (size_t)2 * NP, st));
   } else {
