@@ -201,7 +201,7 @@ def pmc_traffic(args, m, n, world, res):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot
     run inside the timed program): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction), valid for the
     workload and schedule the profile was taken on, else null."""
-    f = Path(__file__).resolve().parent / "profiles" / "r01_nw1m_pmc_v4_persistent.json"
+    f = Path(__file__).resolve().parent / "profiles" / "r01_nw1m_pmc_v5_persistent.json"
     if world != 1 or args.kind != "nw" or (m, n) != (1000000, 999747) or res.n_launches != 1 or not f.exists():
         return None
     return json.loads(f.read_text())["derived"]["hbm_traffic_bytes_per_launch"]
@@ -344,7 +344,7 @@ def main():
                 "unit": "T int32 lane-ops/s",
                 "frac": round(achieved / VALU_PEAK_TOPS, 4),
                 "traffic": pmc_traffic(args, m, n, world, res),
-                "traffic_note": "HBM bytes per launch, WRITE_SIZE + 2 x FETCH_SIZE of profiles/r01_nw1m_pmc_v4_persistent.json; "
+                "traffic_note": "HBM bytes per launch, WRITE_SIZE + 2 x FETCH_SIZE of profiles/r01_nw1m_pmc_v5_persistent.json; "
                                 "algorithmic: 0.25 B/cell trace + 16 B per strip column of bottom-row hand-off",
                 "kernel": "fill_persistent" if res.n_launches < 100 else "fill_tile",
                 "ops_per_cell": ops,

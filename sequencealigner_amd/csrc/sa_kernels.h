@@ -55,7 +55,7 @@ struct FillArgs {
   int* botF;             // [ring][NP]
   int ring;              // 2: strips alternate between two slots; S+1: every strip keeps its own (checkpoints)
   int* state;            // [S][NF][64] lane state carried from tile to tile
-  uint32_t* trace;       // [S][W][64][K]; null: codes are computed but not stored (checkpoint pass)
+  uint32_t* trace;       // [S][W][64][K]; unused by FLAG_NOTRACE kernels (score-only / checkpoint pass)
   int trace_s0;          // strip whose codes sit at the start of `trace` (banded recomputation)
   int* rowbest;          // SW: best score per row
   int* rowbestc;         // SW: first column (0-based) attaining it
@@ -96,7 +96,7 @@ __device__ __forceinline__ int dpp_shl1(int old, int src) {  // lane l <- src of
 // rotate-left whose lane 63 is a don't-care: no tie to an old value, so no register copy
 __device__ __forceinline__ int dpp_shl1_any(int src) { return __builtin_amdgcn_mov_dpp(src, 0x130, 0xf, 0xf, false); }
 
-enum { FLAG_FRAC = 1, FLAG_DUMP = 2, FLAG_PERSIST = 4 };
+enum { FLAG_FRAC = 1, FLAG_DUMP = 2, FLAG_PERSIST = 4, FLAG_NOTRACE = 8 };
 #ifndef SA_SUB_UNROLL
 #define SA_SUB_UNROLL 4
 #endif
@@ -340,9 +340,10 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
         st.bestc[k] = better ? cbase + 15 - (int)(sbk[k] & 15u) : st.bestc[k];
       }
     }
-    // (the compiler sinks the 16 x K code-packing ops of the sub-block into this branch: a score-only /
-    // checkpoint pass skips them, which is where its ~10 % come from -- not from the memory system)
-    if (a.trace) store_trace<K>(tdst, tacc);
+    // A compile-time switch: score-only / checkpoint passes (FLAG_NOTRACE) drop the stores and with them
+    // the 16 x K packing ops.  As a run-time test on a.trace it cost the normal path 2.5 %: the compiler
+    // sank all packing ops of the sub-block into the branch instead of spreading them over the steps.
+    if (!(FLAGS & FLAG_NOTRACE)) store_trace<K>(tdst, tacc);
     tdst += 64 * K;
     hook(sub);
   }
@@ -627,7 +628,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
           if (b > 0) {
             // blocks 0..b-1 are complete once everything older than this sub-block's code
             // stores has retired (vmcnt counts loads and stores together, in issue order)
-            if (!a.trace)  // score-only / checkpoint pass: no code stores were issued in between
+            if (FLAGS & FLAG_NOTRACE)  // score-only / checkpoint pass: no code stores were issued in between
               asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else if (K == 8)
               asm volatile("s_waitcnt vmcnt(2)" ::: "memory");

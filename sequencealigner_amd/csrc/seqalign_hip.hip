@@ -221,13 +221,24 @@ void launch_fill(int K, int fl, dim3 grid, size_t lds, hipStream_t st, const Fil
   }
 }
 
+// notrace: the FLAG_NOTRACE instances (score-only calls, the checkpoint pass): no codes are packed or stored
 template <int KIND>
-void launch_persistent(int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a) {
+void launch_persistent(int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a, bool notrace = false) {
+  const dim3 blk(64 * kWavesPerBlock);
+  if (notrace) {
+    switch (K) {
+      case 1: hipLaunchKernelGGL((fill_persistent<KIND, 1, FLAG_NOTRACE>), grid, blk, lds, st, a); break;
+      case 2: hipLaunchKernelGGL((fill_persistent<KIND, 2, FLAG_NOTRACE>), grid, blk, lds, st, a); break;
+      case 4: hipLaunchKernelGGL((fill_persistent<KIND, 4, FLAG_NOTRACE>), grid, blk, lds, st, a); break;
+      default: hipLaunchKernelGGL((fill_persistent<KIND, 8, FLAG_NOTRACE>), grid, blk, lds, st, a); break;
+    }
+    return;
+  }
   switch (K) {
-    case 1: hipLaunchKernelGGL((fill_persistent<KIND, 1, 0>), grid, dim3(64 * kWavesPerBlock), lds, st, a); break;
-    case 2: hipLaunchKernelGGL((fill_persistent<KIND, 2, 0>), grid, dim3(64 * kWavesPerBlock), lds, st, a); break;
-    case 4: hipLaunchKernelGGL((fill_persistent<KIND, 4, 0>), grid, dim3(64 * kWavesPerBlock), lds, st, a); break;
-    default: hipLaunchKernelGGL((fill_persistent<KIND, 8, 0>), grid, dim3(64 * kWavesPerBlock), lds, st, a); break;
+    case 1: hipLaunchKernelGGL((fill_persistent<KIND, 1, 0>), grid, blk, lds, st, a); break;
+    case 2: hipLaunchKernelGGL((fill_persistent<KIND, 2, 0>), grid, blk, lds, st, a); break;
+    case 4: hipLaunchKernelGGL((fill_persistent<KIND, 4, 0>), grid, blk, lds, st, a); break;
+    default: hipLaunchKernelGGL((fill_persistent<KIND, 8, 0>), grid, blk, lds, st, a); break;
   }
 }
 
@@ -371,7 +382,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   // recomputes the strips it walks through, a band at a time.  Score-only calls
   // store no codes at all.
   const size_t strip_trace_bytes = (size_t)W * 64 * K * 4;
-  const bool no_tb = (flags & SA_FLAG_NO_TRACEBACK) != 0 && !sd;
+  const bool no_tb = (flags & SA_FLAG_NO_TRACEBACK) != 0 && !sd && persist;
   size_t budget = ctx->trace_budget;
   if (!budget) {
     size_t free_b = 0, total_b = 0;
@@ -542,11 +553,11 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   if (persist) {
     const dim3 grid(std::min((S + kWavesPerBlock - 1) / kWavesPerBlock, ctx->n_cu * std::max(1, ctx->wps)));
     if (kind == KIND_NW)
-      launch_persistent<KIND_NW>(K, grid, lds, st, a);
+      launch_persistent<KIND_NW>(K, grid, lds, st, a, ckpt || no_tb);
     else if (kind == KIND_SW)
-      launch_persistent<KIND_SW>(K, grid, lds, st, a);
+      launch_persistent<KIND_SW>(K, grid, lds, st, a, ckpt || no_tb);
     else
-      launch_persistent<KIND_LCS>(K, grid, lds, st, a);
+      launch_persistent<KIND_LCS>(K, grid, lds, st, a, ckpt || no_tb);
     launches = 1;
     // border hand-offs, all enqueued now and resolved on the device while the fill runs
     for (int64_t k = 0; k < n_chunks && (a.rows_in || a.chunk_done); ++k) {

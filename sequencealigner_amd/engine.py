@@ -107,7 +107,10 @@ class AlignResult:
 
 
 def lib_path() -> Path:
-    return _PKG / _LIB_NAME
+    # SA_LIBRARY: another build of the same library (A/B measurements of kernel variants)
+    import os
+
+    return Path(os.environ["SA_LIBRARY"]) if os.environ.get("SA_LIBRARY") else _PKG / _LIB_NAME
 
 
 _lib = None
