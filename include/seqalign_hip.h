@@ -149,6 +149,16 @@ int sa_sw_batch_align(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, co
                       float* kernel_ms);
 void sa_free_pool(uint8_t* pool);
 
+/* Many independent pairs, global alignment: globalalign()'s fill + traceback (main.cpp:691-818) applied
+ * to every pair -- the shape of the seed_aligner's per-segment align_segment_globally calls
+ * (main_fmindex.cpp:1049-1143, one per anchored segment).  score[k] = S[m][n]; the op list of pair k
+ * (end (m, n) -> start (0, 0), border walks included) sits in the pool as for sa_sw_batch_align.
+ * A pair with an empty side is the reference's border walk.  Integral, non-positive penalties. */
+int sa_nw_batch_align(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x,
+                      const int64_t* off_y, const int32_t* len_y, int64_t n_pairs, const sa_scoring* sc,
+                      int32_t* score, int64_t* ops_off, int32_t* n_ops, uint8_t** ops_pool,
+                      int64_t* ops_pool_bytes, float* kernel_ms);
+
 /* ---- one long pair over several GPUs: column stripes ----
  *
  * Replaces the reference's MPI row-block chain (main.cpp:1050-1147, 1151-1177), which is serial;

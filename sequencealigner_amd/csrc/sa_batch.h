@@ -268,6 +268,239 @@ __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
   }
 }
 
+// ---- global alignment (Needleman-Wunsch) of many pairs --------------------------------------
+// Same sweep as the TRACE instances above with the reference's NW recurrence (main.cpp:622-672:
+// no floors, tie-break M over E over F via the tags) and its borders (main.cpp:601-620, 719-729):
+// H[i][0] = go + (i-1) max(go, ge), E[i][0] = -inf, H[0][j] = go + (j-1) ge, F[0][j] = -inf,
+// H[0][0] = 0 -- closed forms of the reference's chains for the integral penalties this path
+// admits.  Borders need the cells outside [0, n) to keep their hands off the state, so sub-blocks
+// that touch the first 64 or the last 64+ steps run a masked instance (MASK) that freezes a
+// lane's registers while its column is outside the matrix; everything in between is unmasked.
+// After the sweep every lane holds H[i][n] of its rows, the score is H[m][n].
+template <int K, bool MASK>
+__device__ __forceinline__ void nw_batch_steps(int t0, int lane, int n, int go, int ge, const char* ldsLane, const uint8_t* yenc,
+                                               int (&H)[K], int (&E)[K], int& passH, int& passF, int& dprev, int& ypass, int& yb,
+                                               int& yv, uint32_t (&pw)[BatchGeo<K>::PW], uint32_t* tdst) {
+  using G = BatchGeo<K>;
+  uint32_t tacc[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) tacc[k] = 0;
+#pragma unroll
+  for (int u = 0; u < 16; ++u) {
+    const int t = t0 + u;
+    // lane 0 sits under row 0 of the matrix: H[0][t+1] = go + t ge (tag-free), F[0][.] = -inf
+    int up = dpp_shr1(go + t * ge, passH);
+    int uf = dpp_shr1(kNeg, passF);
+    if (u == 15 && ((t0 + 16) & 63) == 0) yb = (int)yenc[t + 1 + lane] * G::ROWB;
+    ypass = yv;
+    const int yv_next = dpp_shr1(yb, ypass);
+    yb = dpp_shl1(yb, yb);
+    uint32_t pw_next[G::PW];
+    if (G::PW == 1) {
+      pw_next[0] = *reinterpret_cast<const uint32_t*>(ldsLane + yv_next);
+    } else if (G::PW == 2) {
+      const uint2 q = *reinterpret_cast<const uint2*>(ldsLane + yv_next);
+      pw_next[0] = q.x;
+      pw_next[G::PW - 1] = q.y;
+    } else {
+      const uint4 q = *reinterpret_cast<const uint4*>(ldsLane + yv_next);
+      pw_next[0] = q.x;
+      pw_next[1 % G::PW] = q.y;
+      pw_next[2 % G::PW] = q.z;
+      pw_next[3 % G::PW] = q.w;
+    }
+    const int c = t - lane;
+    const bool act = !MASK || (c >= 0 && c < n);
+    int diag = dprev;
+    if (MASK)
+      dprev = act ? up : dprev;
+    else
+      dprev = up;
+    int f_last = passF;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int sg = (int)(int8_t)(pw[k / 4] >> (8 * (k & 3)));  // 4 sigma + 2
+      const int left = H[k];
+      int f = max(up + go, uf + ge);            // tag 0
+      int e = max(left + go + 1, E[k] + ge);    // tag 1
+      const int mv = diag + sg;                 // tag 2
+      const int ht = max(max(mv, e), f);
+      tacc[k] = __builtin_amdgcn_alignbit((uint32_t)ht, tacc[k], 2);
+      int h = ht & ~3;
+      if (MASK) {
+        h = act ? h : left;
+        e = act ? e : E[k];
+        f = act ? f : f_last;
+      }
+      E[k] = e;
+      diag = left;
+      H[k] = h;
+      up = h;
+      uf = f;
+      f_last = f;
+    }
+    passH = up;
+    passF = uf;
+    yv = yv_next;
+#pragma unroll
+    for (int i = 0; i < G::PW; ++i) pw[i] = pw_next[i];
+  }
+#pragma unroll
+  for (int k = 0; k < K; ++k) tdst[k] = tacc[k];
+}
+
+template <int K>
+__global__ void __launch_bounds__(64) nw_batch_kernel(const BatchArgs a) {
+  using G = BatchGeo<K>;
+  extern __shared__ uint32_t lds[];
+  const int lane = threadIdx.x;
+  const PairDesc pd = a.desc[blockIdx.x];
+  const int m = pd.m, n = pd.n, alpha = a.alpha;
+  uint32_t* prof = lds;
+  uint8_t* yenc = reinterpret_cast<uint8_t*>(lds + (alpha + 1) * 64 * G::PW);
+  uint8_t* map = yenc + kBatchMaxN + 256;
+  int8_t* subt = reinterpret_cast<int8_t*>(map + 256);
+  for (int i = lane; i < 256; i += 64) map[i] = a.idx256[i];
+  for (int i = lane; i < alpha * alpha; i += 64) subt[i] = a.sub[i];
+  __syncthreads();
+  bool bad = false;
+  const uint8_t* y = a.seqs + pd.off_y;
+  const int ylen = ((n + 63 + 63) / 64) * 64 + 128;
+  for (int i = lane; i < ylen; i += 64) {
+    uint8_t v = (uint8_t)alpha;
+    if (i < n) {
+      v = map[y[i]];
+      bad |= (v == 255);
+      if (v == 255) v = 0;
+    }
+    yenc[i] = v;
+  }
+  const uint8_t* x = a.seqs + pd.off_x;
+  int xi[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int r = lane * K + k;
+    int v = -1;
+    if (r < m) {
+      v = map[x[r]];
+      bad |= (v == 255);
+      if (v == 255) v = 0;
+    }
+    xi[k] = v;
+  }
+  for (int sym = 0; sym <= alpha; ++sym) {
+    uint32_t w[G::PW];
+#pragma unroll
+    for (int i = 0; i < G::PW; ++i) w[i] = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      int v = (sym == alpha || xi[k] < 0) ? 0 : (int)subt[xi[k] * alpha + sym];
+      v = 4 * v + 2;
+      w[k / 4] |= (uint32_t)(uint8_t)(int8_t)v << (8 * (k & 3));
+    }
+#pragma unroll
+    for (int i = 0; i < G::PW; ++i) prof[(sym * 64 + lane) * G::PW + i] = w[i];
+  }
+  __syncthreads();
+
+  const char* ldsLane = reinterpret_cast<const char*>(prof) + lane * 4 * G::PW;
+  const int go = 4 * a.go, ge = 4 * a.ge, gmax = max(go, ge);
+  int H[K], E[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int i = lane * K + k + 1;          // matrix row of this register
+    H[k] = go + (i - 1) * gmax;              // H[i][0]
+    E[k] = kNeg | 1;                         // E[i][0] = -inf, tag 1
+  }
+  const int r0 = lane * K;                   // H[r0][0]: the diagonal of the lane's first cell
+  int dprev = r0 == 0 ? 0 : go + (r0 - 1) * gmax;
+  int passH = H[K - 1], passF = kNeg;
+  int ypass = alpha * G::ROWB;
+  const int nsteps = ((n + 63 + 15) / 16) * 16;
+  int yb = (int)yenc[lane] * G::ROWB;
+  int yv = dpp_shr1(yb, ypass);
+  yb = dpp_shl1(yb, yb);
+  uint32_t pw[G::PW];
+  if (G::PW == 1) {
+    pw[0] = *reinterpret_cast<const uint32_t*>(ldsLane + yv);
+  } else if (G::PW == 2) {
+    const uint2 q = *reinterpret_cast<const uint2*>(ldsLane + yv);
+    pw[0] = q.x;
+    pw[G::PW - 1] = q.y;
+  } else {
+    const uint4 q = *reinterpret_cast<const uint4*>(ldsLane + yv);
+    pw[0] = q.x;
+    pw[1 % G::PW] = q.y;
+    pw[2 % G::PW] = q.z;
+    pw[3 % G::PW] = q.w;
+  }
+  uint32_t* tdst = a.trace + pd.off_trace + (size_t)lane * K;
+#pragma unroll 1
+  for (int t0 = 0; t0 < nsteps; t0 += 16) {
+    // unmasked only if every lane's column is inside [0, n) for all 16 steps
+    if (t0 >= 64 && t0 + 15 < n)
+      nw_batch_steps<K, false>(t0, lane, n, go, ge, ldsLane, yenc, H, E, passH, passF, dprev, ypass, yb, yv, pw, tdst);
+    else
+      nw_batch_steps<K, true>(t0, lane, n, go, ge, ldsLane, yenc, H, E, passH, passF, dprev, ypass, yb, yv, pw, tdst);
+    tdst += 64 * K;
+  }
+  // H[m][n]: row m-1 lives in lane (m-1)/K, register (m-1)%K
+  const int lm = (m - 1) / K, km = (m - 1) - lm * K;
+  int hm = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    if (k == km) hm = H[k];
+  hm = __shfl(hm, lm);
+  const unsigned long long anybad = __ballot(bad);
+  if (lane == 0) {
+    a.score[pd.idx] = anybad ? INT_MIN : (hm >> 2);
+    a.end_i[pd.idx] = anybad ? 0 : m;
+    a.end_j[pd.idx] = anybad ? 0 : n;
+    if (anybad) *a.err = 1;
+  }
+}
+
+// One thread per pair: from (m, n) along the stored winners (M 2, E 1, F 0) to a border, then the
+// border walk of the reference (row 0: left moves, column 0: up moves; main.cpp:781-816).
+__global__ void nw_batch_traceback(const BatchArgs a) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.n_desc) return;
+  const PairDesc pd = a.desc[q];
+  const int K = (pd.m + 63) / 64;
+  int i = pd.m, j = pd.n;
+  const uint32_t* tr = a.trace + pd.off_trace;
+  uint32_t* out = reinterpret_cast<uint32_t*>(a.ops + pd.off_ops);
+  int nops = 0;
+  uint32_t acc = 0;
+  if (a.score[pd.idx] != INT_MIN) {
+    while (i > 0 || j > 0) {
+      uint32_t op;
+      if (i == 0) {
+        op = 1u;
+      } else if (j == 0) {
+        op = 2u;
+      } else {
+        const int r = i - 1, c = j - 1;
+        const int l = r / K, k = r - l * K;
+        const int t = c + l;
+        op = 2u - ((tr[((size_t)(t >> 4) * 64 + l) * K + k] >> (2 * (t & 15))) & 3u);
+      }
+      acc |= op << (8 * (nops & 3));
+      if ((nops & 3) == 3) {
+        out[nops >> 2] = acc;
+        acc = 0;
+      }
+      ++nops;
+      if (op != 1u) --i;
+      if (op != 2u) --j;
+    }
+    if (nops & 3) out[nops >> 2] = acc;
+  }
+  a.n_ops[pd.idx] = nops;
+  a.start_i[pd.idx] = 0;
+  a.start_j[pd.idx] = 0;
+}
+
 // dwords of codes one pair occupies
 inline long long batch_trace_dwords(int m, int n) {
   const int K = (m + 63) / 64;

@@ -940,6 +940,32 @@ void launch_batch(hipStream_t st, int count, int alpha, const BatchArgs& a, bool
     hipLaunchKernelGGL((sw_batch_kernel<K, false>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha), st, a);
 }
 
+template <int K>
+void launch_nw_batch(hipStream_t st, int count, int alpha, const BatchArgs& a) {
+  hipLaunchKernelGGL((nw_batch_kernel<K>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha), st, a);
+}
+
+void launch_nw_batch_k(int K, hipStream_t st, int count, int alpha, const BatchArgs& a) {
+  switch (K) {
+    case 1: launch_nw_batch<1>(st, count, alpha, a); break;
+    case 2: launch_nw_batch<2>(st, count, alpha, a); break;
+    case 3: launch_nw_batch<3>(st, count, alpha, a); break;
+    case 4: launch_nw_batch<4>(st, count, alpha, a); break;
+    case 5: launch_nw_batch<5>(st, count, alpha, a); break;
+    case 6: launch_nw_batch<6>(st, count, alpha, a); break;
+    case 7: launch_nw_batch<7>(st, count, alpha, a); break;
+    case 8: launch_nw_batch<8>(st, count, alpha, a); break;
+    case 9: launch_nw_batch<9>(st, count, alpha, a); break;
+    case 10: launch_nw_batch<10>(st, count, alpha, a); break;
+    case 11: launch_nw_batch<11>(st, count, alpha, a); break;
+    case 12: launch_nw_batch<12>(st, count, alpha, a); break;
+    case 13: launch_nw_batch<13>(st, count, alpha, a); break;
+    case 14: launch_nw_batch<14>(st, count, alpha, a); break;
+    case 15: launch_nw_batch<15>(st, count, alpha, a); break;
+    default: launch_nw_batch<16>(st, count, alpha, a); break;
+  }
+}
+
 void launch_batch_k(int K, hipStream_t st, int count, int alpha, const BatchArgs& a, bool trace = false) {
   switch (K) {
     case 1: launch_batch<1>(st, count, alpha, a, trace); break;
@@ -1007,6 +1033,7 @@ void pool_release(uint8_t* pool) {
 
 // Outputs of the aligning variant (sa_sw_batch_align): per pair the 'X' cell and the op list.
 struct BatchAlign {
+  int kind;           // KIND_SW: local alignments; KIND_NW: global alignments (end = (m, n), start = (0, 0))
   int32_t* start_i;
   int32_t* start_j;
   int64_t* ops_off;   // byte offset of the pair's ops in the pool: sum over earlier pairs of (m + n) rounded up to 4
@@ -1025,7 +1052,8 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
   if (!ctx) return SA_ERR_ARG;
   if (kernel_ms) *kernel_ms = 0.f;
   if (al) {
-    if (!al->start_i || !al->start_j || !al->ops_off || !al->n_ops || !al->pool) return fail(ctx, SA_ERR_ARG, "bad batch arguments");
+    if ((al->kind == KIND_SW && (!al->start_i || !al->start_j)) || !al->ops_off || !al->n_ops || !al->pool)
+      return fail(ctx, SA_ERR_ARG, "bad batch arguments");
     *al->pool = nullptr;
     if (al->pool_bytes) *al->pool_bytes = 0;
   }
@@ -1050,7 +1078,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
       if (len_x[k] < 0 || len_y[k] < 0) return fail(ctx, SA_ERR_ARG, "negative length in pair %lld", (long long)k);
       al->ops_off[k] = pool_total;
       al->n_ops[k] = 0;
-      al->start_i[k] = al->start_j[k] = 0;
+      if (al->start_i) al->start_i[k] = al->start_j[k] = 0;
       pool_total += ((int64_t)len_x[k] + len_y[k] + 3) & ~3LL;
     }
     *al->pool = pool_acquire((size_t)std::max<int64_t>(pool_total, 4));
@@ -1071,7 +1099,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
   // group by rows-per-lane K = ceil(m/64); counting sort keeps the caller's order inside a group
   std::vector<PairDesc> desc;
   desc.reserve((size_t)n_pairs);
-  std::vector<int64_t> slow;
+  std::vector<int64_t> slow, empty_side;
   std::vector<int> group_count(17, 0), group_nmax(17, 0);
   int64_t pool_end = 0;
   for (int64_t k = 0; k < n_pairs; ++k) {
@@ -1080,6 +1108,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     if (len_x[k] == 0 || len_y[k] == 0) {
       score[k] = 0;
       end_i[k] = end_j[k] = 0;
+      if (al && al->kind == KIND_NW) empty_side.push_back(k);  // a border walk (main.cpp: row 0 / column 0)
     } else if (len_x[k] > kBatchMaxM || len_y[k] > kBatchMaxN - 200) {
       slow.push_back(k);
     } else {
@@ -1183,12 +1212,18 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
         int CB = 8;
         while ((1 << CB) < group_nmax[K] + 160) ++CB;
         a.CB = CB;
-        launch_batch_k(K, st, a.n_desc, alpha, a, al != nullptr);
+        if (al && al->kind == KIND_NW)
+          launch_nw_batch_k(K, st, a.n_desc, alpha, a);
+        else
+          launch_batch_k(K, st, a.n_desc, alpha, a, al != nullptr);
       }
       if (al) {
         a.desc = (const PairDesc*)ctx->b_desc.p + ch.lo;
         a.n_desc = (int)(ch.hi - ch.lo);
-        hipLaunchKernelGGL(sw_batch_traceback, dim3((a.n_desc + 63) / 64), dim3(64), 0, st, a);
+        if (al->kind == KIND_NW)
+          hipLaunchKernelGGL(nw_batch_traceback, dim3((a.n_desc + 63) / 64), dim3(64), 0, st, a);
+        else
+          hipLaunchKernelGGL(sw_batch_traceback, dim3((a.n_desc + 63) / 64), dim3(64), 0, st, a);
       }
       HIPCK(ctx, hipGetLastError());
       HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
@@ -1211,22 +1246,27 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
       if (al) {
         const bool bad = score[d.idx] == INT32_MIN;
         al->n_ops[d.idx] = bad ? 0 : h_out[(size_t)3 * n_pairs + d.idx];
-        al->start_i[d.idx] = bad ? 0 : h_out[(size_t)4 * n_pairs + d.idx];
-        al->start_j[d.idx] = bad ? 0 : h_out[(size_t)5 * n_pairs + d.idx];
+        if (al->start_i) {
+          al->start_i[d.idx] = bad ? 0 : h_out[(size_t)4 * n_pairs + d.idx];
+          al->start_j[d.idx] = bad ? 0 : h_out[(size_t)5 * n_pairs + d.idx];
+        }
       }
     }
   }
   for (int64_t k : slow) {
     sa_result r;
-    const int rc1 = run_pair(ctx, KIND_SW, seqs + off_x[k], len_x[k], seqs + off_y[k], len_y[k], sc, al ? 0 : SA_FLAG_NO_TRACEBACK, &r);
+    const int rc1 = run_pair(ctx, al ? al->kind : KIND_SW, seqs + off_x[k], len_x[k], seqs + off_y[k], len_y[k], sc,
+                             al ? 0 : SA_FLAG_NO_TRACEBACK, &r);
     if (rc1 == SA_OK) {
       score[k] = (int32_t)r.score;
       end_i[k] = (int32_t)r.end_i;
       end_j[k] = (int32_t)r.end_j;
       if (al) {
         al->n_ops[k] = (int32_t)r.n_ops;
-        al->start_i[k] = (int32_t)r.start_i;
-        al->start_j[k] = (int32_t)r.start_j;
+        if (al->start_i) {
+          al->start_i[k] = (int32_t)r.start_i;
+          al->start_j[k] = (int32_t)r.start_j;
+        }
         if (r.n_ops) memcpy(*al->pool + al->ops_off[k], r.ops, (size_t)r.n_ops);
       }
       if (kernel_ms) *kernel_ms += r.kernel_fill_ms;
@@ -1237,6 +1277,18 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     } else {
       return rc1;
     }
+    sa_free_result(&r);
+  }
+  for (int64_t k : empty_side) {  // global alignment against nothing: the reference's border chain and walk
+    std::vector<int> rowb, colb;
+    border_chains(KIND_NW, len_x[k], len_y[k], sc, rowb, colb);
+    sa_result r{};
+    border_only_result(KIND_NW, len_x[k], len_y[k], rowb, colb, &r);
+    score[k] = (int32_t)r.score;
+    end_i[k] = len_x[k];
+    end_j[k] = len_y[k];
+    al->n_ops[k] = (int32_t)r.n_ops;
+    if (r.n_ops) memcpy(*al->pool + al->ops_off[k], r.ops, (size_t)r.n_ops);
     sa_free_result(&r);
   }
   guard.keep = true;
@@ -1397,8 +1449,18 @@ int sa_sw_batch_align(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, co
                       const int32_t* len_y, int64_t n_pairs, const sa_scoring* sc, int32_t* score, int32_t* end_i,
                       int32_t* end_j, int32_t* start_i, int32_t* start_j, int64_t* ops_off, int32_t* n_ops,
                       uint8_t** ops_pool, int64_t* ops_pool_bytes, float* kernel_ms) {
-  const BatchAlign al{start_i, start_j, ops_off, n_ops, ops_pool, ops_pool_bytes};
+  const BatchAlign al{KIND_SW, start_i, start_j, ops_off, n_ops, ops_pool, ops_pool_bytes};
   return run_batch(ctx, seqs, off_x, len_x, off_y, len_y, n_pairs, sc, score, end_i, end_j, kernel_ms, &al);
+}
+
+int sa_nw_batch_align(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x, const int64_t* off_y,
+                      const int32_t* len_y, int64_t n_pairs, const sa_scoring* sc, int32_t* score, int64_t* ops_off,
+                      int32_t* n_ops, uint8_t** ops_pool, int64_t* ops_pool_bytes, float* kernel_ms) {
+  if (!ctx) return SA_ERR_ARG;
+  if (n_pairs < 0 || (n_pairs > 0 && !score)) return fail(ctx, SA_ERR_ARG, "bad batch arguments");
+  std::vector<int32_t> ei((size_t)std::max<int64_t>(n_pairs, 1)), ej((size_t)std::max<int64_t>(n_pairs, 1));
+  const BatchAlign al{KIND_NW, nullptr, nullptr, ops_off, n_ops, ops_pool, ops_pool_bytes};
+  return run_batch(ctx, seqs, off_x, len_x, off_y, len_y, n_pairs, sc, score, ei.data(), ej.data(), kernel_ms, &al);
 }
 
 void sa_free_pool(uint8_t* pool) { pool_release(pool); }

@@ -143,3 +143,74 @@ def test_batch_align_invalid_residue(engine, oracle):
     assert b.score[0] == np.iinfo(np.int32).min and b.n_ops[0] == 0
     w = oracle.sw(pool[0:8], pool[16:24], "dna")
     assert b.score[1] == w.score and np.array_equal(b.ops(1), w.ops)
+
+
+# ---- sa_nw_batch_align: global alignments per pair ----
+def compare_nw_align(engine, oracle, pool, ox, lx, oy, ly, mode="protein", go=-5.0, ge=-1.0):
+    b = engine.nw_batch_align(pool, ox, lx, oy, ly, mode, go, ge)
+    assert b.rc == 0
+    for k in range(len(ox)):
+        x = pool[ox[k]:ox[k] + lx[k]]
+        y = pool[oy[k]:oy[k] + ly[k]]
+        w = oracle.nw(x, y, mode, go, ge)
+        assert int(b.score[k]) == w.score, (k, lx[k], ly[k], int(b.score[k]), w.score)
+        assert np.array_equal(b.ops(k), w.ops), (k, lx[k], ly[k])
+    return b
+
+
+def test_nw_batch_align_all_row_groups(engine, oracle):
+    rng = np.random.default_rng(21)
+    lens = [(m, int(rng.integers(1, 500))) for m in list(range(1, 70, 3)) + list(range(120, 1030, 61)) + [63, 64, 65, 127, 128, 129, 1023, 1024]]
+    compare_nw_align(engine, oracle, *make_pool(rng, lens))
+    compare_nw_align(engine, oracle, *make_pool(rng, lens, PROT24, related=True))
+    # short targets (every sub-block masked), targets just around the 64-step boundaries
+    lens = [(int(rng.integers(1, 400)), n) for n in (1, 2, 15, 16, 17, 47, 48, 49, 63, 64, 65, 79, 80, 81, 127, 128, 129, 143, 144, 145)]
+    compare_nw_align(engine, oracle, *make_pool(rng, lens, related=True))
+
+
+def test_nw_batch_align_gaps_dna_ties_and_edges(engine, oracle):
+    rng = np.random.default_rng(22)
+    lens = [(int(rng.integers(1, 300)), int(rng.integers(1, 300))) for _ in range(40)]
+    for go, ge in [(-10.0, -1.0), (-2.0, -2.0), (0.0, 0.0), (-1.0, -3.0), (-3.0, 0.0)]:
+        compare_nw_align(engine, oracle, *make_pool(rng, lens, related=True), go=go, ge=ge)
+    compare_nw_align(engine, oracle, *make_pool(rng, lens, "ACGT", related=True), mode="dna")
+    compare_nw_align(engine, oracle, *make_pool(rng, [(30, 30)] * 10 + [(200, 90)] * 3, "A"), mode="dna")  # tie storms
+    # empty sides, both empty, and a pair beyond the batch kernel's limits (single-pair path)
+    pool = np.frombuffer(b"ACGTACGT" + b"ACGT" * 300 + b"ACGTT" * 260, np.uint8)
+    ox = np.array([0, 0, 0, 8])
+    lx = np.array([8, 0, 0, 1200], np.int32)
+    oy = np.array([0, 0, 0, 8 + 1200])
+    ly = np.array([0, 5, 0, 1300], np.int32)
+    compare_nw_align(engine, oracle, pool, ox, lx, oy, ly, mode="dna")
+
+
+def test_nw_batch_align_seed_segments(engine):
+    """the seed_aligner's anchored segments (tests/golden/seed_segments.json, from the compiled
+    reference's align_segment_globally) in ONE call per score table and gap setting"""
+    from seed_common import load, replay, scoring_arrays
+
+    gold = load()
+    modes = ["dna", "protein"]
+    for mode in (0, 1):
+        sub, idx = scoring_arrays(gold["tables"][modes[mode]])
+        for go, ge in sorted({(c["go"], c["ge"]) for c in gold["nw"]}):
+            if go != int(go) or ge != int(ge):
+                continue  # fractional penalties go through sa_nw (tests/test_gpu_seed_segments.py)
+            cases = [c for c in gold["nw"] if c["mode"] == mode and (c["go"], c["ge"]) == (go, ge) and (c["s1"] or c["s2"])]
+            if not cases:
+                continue
+            pool, ox, lx, oy, ly, pos = [], [], [], [], [], 0
+            for c in cases:
+                for s, o, l in ((c["s1"], ox, lx), (c["s2"], oy, ly)):
+                    o.append(pos)
+                    l.append(len(s))
+                    pool.append(s)
+                    pos += len(s)
+            buf = np.frombuffer(("".join(pool) or "A").encode("latin-1"), np.uint8)
+            b = engine.nw_batch_align(buf, np.array(ox), np.array(lx, np.int32), np.array(oy), np.array(ly, np.int32), modes[mode], go, ge,
+                                      sub=sub, idx256=idx)
+            assert b.rc == 0
+            for k, c in enumerate(cases):
+                if c["s1"] and c["s2"]:
+                    assert int(b.score[k]) == c["score"], c
+                assert replay(c["s1"].encode("latin-1"), c["s2"].encode("latin-1"), b.ops(k)) == (c["a1"], c["a2"]), c
