@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <climits>
+#include <cmath>
 #include <cstring>
 #include <filesystem>
 #include <iostream>
@@ -192,7 +193,68 @@ void run_batch_mode(sa_ctx* ctx, const Options& o) {
     }
     sa_free_pool(ops_pool);
   }
+  if ((o.choice == 1 || o.choice == 4) && o.gap_open == std::floor(o.gap_open) && o.gap_extend == std::floor(o.gap_extend) &&
+      o.gap_open <= 0 && o.gap_extend <= 0) {
+    // global alignments: one engine call for every pair (integral penalties; otherwise the loop below)
+    std::string pool;
+    std::vector<int64_t> ox(np), oy(np), ops_off(np);
+    std::vector<int32_t> lx(np), ly(np), score(np), nops(np);
+    for (int64_t k = 0; k < np; ++k) {
+      ox[k] = (int64_t)pool.size();
+      lx[k] = (int32_t)qs[k].residues.size();
+      pool += qs[k].residues;
+      oy[k] = (int64_t)pool.size();
+      ly[k] = (int32_t)ts[k].residues.size();
+      pool += ts[k].residues;
+    }
+    sa_scoring sc = *sa_builtin_scoring(o.mode);
+    sc.gap_open = o.gap_open;
+    sc.gap_extend = o.gap_extend;
+    uint8_t* ops_pool = nullptr;
+    int64_t pool_bytes = 0;
+    float kms = 0;
+    const auto t0 = std::chrono::high_resolution_clock::now();
+    const int rc = sa_nw_batch_align(ctx, (const uint8_t*)pool.data(), ox.data(), lx.data(), oy.data(), ly.data(), np, &sc, score.data(),
+                                     ops_off.data(), nops.data(), &ops_pool, &pool_bytes, &kms);
+    const auto t1 = std::chrono::high_resolution_clock::now();
+    if (rc != SA_OK && rc != SA_ERR_INVALID_CODE) throw std::runtime_error(std::string("GPU engine: ") + sa_last_error(ctx));
+    const int64_t ms_each = np ? std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count() / np : 0;
+    for (int64_t k = 0; k < np; ++k) {
+      char a[256], b[256];
+      ids(k, a, b);
+      if (score[k] == INT32_MIN) {
+        std::cerr << "Error: pair " << (k + 1) << ": invalid residue for --mode " << (o.mode == SA_MODE_DNA ? "dna" : "protein") << "\n";
+        fprintf(sum, "%lld\t%s\t%s\t%d\t%d\tglobal\tERROR\t\t\t\t\t\n", (long long)k + 1, a, b, lx[k], ly[k]);
+        continue;
+      }
+      const std::string dir = pair_dir(k);
+      sah_job job{};
+      job.outdir = dir.c_str();
+      job.header1 = qs[k].header.c_str();
+      job.header2 = ts[k].header.c_str();
+      job.mode = o.mode;
+      job.gap_open = o.gap_open;
+      job.gap_extend = o.gap_extend;
+      job.x = (const uint8_t*)pool.data() + ox[k];
+      job.m = lx[k];
+      job.y = (const uint8_t*)pool.data() + oy[k];
+      job.n = ly[k];
+      job.score = score[k];
+      job.end_i = lx[k];
+      job.end_j = ly[k];
+      job.ops = ops_pool + ops_off[k];
+      job.n_ops = nops[k];
+      job.time_ms = ms_each;
+      job.verbose = o.verbose;
+      sah_write_global(&job);
+      fprintf(sum, "%lld\t%s\t%s\t%d\t%d\tglobal\t%d\t%d\t%d\t0\t0\t%d\n", (long long)k + 1, a, b, lx[k], ly[k], score[k], lx[k], ly[k], nops[k]);
+    }
+    sa_free_pool(ops_pool);
+  }
+  const bool global_done = (o.choice == 1 || o.choice == 4) && o.gap_open == std::floor(o.gap_open) &&
+                           o.gap_extend == std::floor(o.gap_extend) && o.gap_open <= 0 && o.gap_extend <= 0;
   for (int which : {1, 3}) {
+    if (which == 1 && global_done) continue;
     if (o.choice != which && o.choice != 4) continue;
     for (int64_t k = 0; k < np; ++k) {
       Options ok = o;

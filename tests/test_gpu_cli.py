@@ -117,7 +117,9 @@ def test_cli_batch_mode_equals_single_pair_runs(tmp_path):
             else:
                 assert a == b, (k, name)
     rows = (out / "batch_summary.tsv").read_text().splitlines()
-    assert len(rows) == 1 + len(pairs) and rows[1].split("\t")[:3] == ["1", "Q00000", "T00000"]
+    # --choice 4: one summary row per pair for the local and one for the global alignment
+    assert len(rows) == 1 + 2 * len(pairs) and rows[1].split("\t")[:3] == ["1", "Q00000", "T00000"]
+    assert sorted(r.split("\t")[5] for r in rows[1:]) == ["global"] * len(pairs) + ["local"] * len(pairs)
     # unequal record counts: caught error, exit 0 (main.cpp:1832-1838 behaviour)
     r = subprocess.run([str(PKG / "aligner"), "--query", str(q), "--target", str(tmp_path / "t0.fa"), "--choice", "2", "--mode",
                         "protein", "--outdir", str(tmp_path / "bad"), "--batch"], capture_output=True, text=True, timeout=60)
