@@ -159,6 +159,14 @@ int sa_nw_batch_align(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, co
                       int32_t* score, int64_t* ops_off, int32_t* n_ops, uint8_t** ops_pool,
                       int64_t* ops_pool_bytes, float* kernel_ms);
 
+/* Many independent pairs, LCS: lcs()'s fill + traceback (main.cpp:1575-1640) per pair (the shape of the
+ * seed_aligner's compute_lcs_for_segment calls, main_fmindex.cpp:1145-1207).  score[k] = L[m][n], op
+ * list as above (diagonal moves are the LCS characters). */
+int sa_lcs_batch_align(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x,
+                       const int64_t* off_y, const int32_t* len_y, int64_t n_pairs, int32_t* score,
+                       int64_t* ops_off, int32_t* n_ops, uint8_t** ops_pool, int64_t* ops_pool_bytes,
+                       float* kernel_ms);
+
 /* ---- one long pair over several GPUs: column stripes ----
  *
  * Replaces the reference's MPI row-block chain (main.cpp:1050-1147, 1151-1177), which is serial;

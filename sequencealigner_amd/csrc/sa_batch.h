@@ -501,6 +501,124 @@ __global__ void nw_batch_traceback(const BatchArgs a) {
   a.start_j[pd.idx] = 0;
 }
 
+// ---- LCS of many pairs ------------------------------------------------------------------------
+// lcs() (main.cpp:1575-1640) per pair: raw byte equality, tie between up and left goes to up.  Tagged
+// like the single-pair LCS kernel (registers hold 4 L + 1; diagonal 3, up 2, left 1).  No masking is
+// needed anywhere: columns outside [0, n) carry a symbol that equals no byte, so cells left of
+// column 0 stay at the zero border and cells right of column n-1 keep L[i][n] (L is monotone), and
+// rows beyond m-1 only ever feed rows below them.
+template <int K>
+__global__ void __launch_bounds__(64) lcs_batch_kernel(const BatchArgs a) {
+  extern __shared__ uint32_t lds[];
+  uint8_t* ybytes = reinterpret_cast<uint8_t*>(lds);
+  const int lane = threadIdx.x;
+  const PairDesc pd = a.desc[blockIdx.x];
+  const int m = pd.m, n = pd.n;
+  const uint8_t* y = a.seqs + pd.off_y;
+  const int ylen = ((n + 63 + 63) / 64) * 64 + 128;
+  for (int i = lane; i < ylen; i += 64) ybytes[i] = i < n ? y[i] : 0;
+  const uint8_t* x = a.seqs + pd.off_x;
+  uint32_t xr[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) {
+    const int r = lane * K + k;
+    xr[k] = r < m ? (uint32_t)x[r] : 0x200u;  // a padding row matches nothing
+  }
+  __syncthreads();
+  auto ysym = [&](int pos) { return pos < n ? (int)ybytes[pos] : 0x100; };  // a padding column matches nothing
+  int H[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) H[k] = 1;
+  int passH = 1, dprev = 1;
+  int ypass = 0x100;
+  const int nsteps = ((n + 63 + 15) / 16) * 16;
+  int yb = ysym(lane);
+  uint32_t* tdst = a.trace + pd.off_trace + (size_t)lane * K;
+#pragma unroll 1
+  for (int t0 = 0; t0 < nsteps; t0 += 16) {
+    uint32_t tacc[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) tacc[k] = 0;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int t = t0 + u;
+      int up = dpp_shr1(1, passH);  // lane 0 sits under row 0: L = 0
+      const int yv = dpp_shr1(yb, ypass);
+      yb = dpp_shl1(yb, yb);
+      if (u == 15 && ((t0 + 16) & 63) == 0) yb = ysym(t + 1 + lane);
+      ypass = yv;
+      int diag = dprev;
+      dprev = up;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int left = H[k];
+        const int dc = (xr[k] == (uint32_t)yv) ? diag + 6 : 0;
+        const int ht = max(max(dc, up + 1), left);
+        tacc[k] = __builtin_amdgcn_alignbit((uint32_t)ht, tacc[k], 2);
+        const int h = (ht & ~3) | 1;
+        diag = left;
+        H[k] = h;
+        up = h;
+      }
+      passH = up;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) tdst[k] = tacc[k];
+    tdst += 64 * K;
+  }
+  const int lm = (m - 1) / K, km = (m - 1) - lm * K;
+  int hm = 0;
+#pragma unroll
+  for (int k = 0; k < K; ++k)
+    if (k == km) hm = H[k];
+  hm = __shfl(hm, lm);
+  if (lane == 0) {
+    a.score[pd.idx] = hm >> 2;
+    a.end_i[pd.idx] = m;
+    a.end_j[pd.idx] = n;
+  }
+}
+
+// One thread per pair: lcs() traceback (main.cpp:1602-1635) over the stored codes (3 diagonal, 2 up,
+// 1 left), then the drains along the borders.
+__global__ void lcs_batch_traceback(const BatchArgs a) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.n_desc) return;
+  const PairDesc pd = a.desc[q];
+  const int K = (pd.m + 63) / 64;
+  int i = pd.m, j = pd.n;
+  const uint32_t* tr = a.trace + pd.off_trace;
+  uint32_t* out = reinterpret_cast<uint32_t*>(a.ops + pd.off_ops);
+  int nops = 0;
+  uint32_t acc = 0;
+  while (i > 0 || j > 0) {
+    uint32_t op;
+    if (i == 0) {
+      op = 1u;
+    } else if (j == 0) {
+      op = 2u;
+    } else {
+      const int r = i - 1, c = j - 1;
+      const int l = r / K, k = r - l * K;
+      const int t = c + l;
+      const uint32_t raw = (tr[((size_t)(t >> 4) * 64 + l) * K + k] >> (2 * (t & 15))) & 3u;
+      op = raw == 3u ? 0u : raw;
+    }
+    acc |= op << (8 * (nops & 3));
+    if ((nops & 3) == 3) {
+      out[nops >> 2] = acc;
+      acc = 0;
+    }
+    ++nops;
+    if (op != 1u) --i;
+    if (op != 2u) --j;
+  }
+  if (nops & 3) out[nops >> 2] = acc;
+  a.n_ops[pd.idx] = nops;
+  a.start_i[pd.idx] = 0;
+  a.start_j[pd.idx] = 0;
+}
+
 // dwords of codes one pair occupies
 inline long long batch_trace_dwords(int m, int n) {
   const int K = (m + 63) / 64;

@@ -966,6 +966,32 @@ void launch_nw_batch_k(int K, hipStream_t st, int count, int alpha, const BatchA
   }
 }
 
+template <int K>
+void launch_lcs_batch(hipStream_t st, int count, const BatchArgs& a) {
+  hipLaunchKernelGGL((lcs_batch_kernel<K>), dim3(count), dim3(64), (size_t)kBatchMaxN + 512, st, a);
+}
+
+void launch_lcs_batch_k(int K, hipStream_t st, int count, const BatchArgs& a) {
+  switch (K) {
+    case 1: launch_lcs_batch<1>(st, count, a); break;
+    case 2: launch_lcs_batch<2>(st, count, a); break;
+    case 3: launch_lcs_batch<3>(st, count, a); break;
+    case 4: launch_lcs_batch<4>(st, count, a); break;
+    case 5: launch_lcs_batch<5>(st, count, a); break;
+    case 6: launch_lcs_batch<6>(st, count, a); break;
+    case 7: launch_lcs_batch<7>(st, count, a); break;
+    case 8: launch_lcs_batch<8>(st, count, a); break;
+    case 9: launch_lcs_batch<9>(st, count, a); break;
+    case 10: launch_lcs_batch<10>(st, count, a); break;
+    case 11: launch_lcs_batch<11>(st, count, a); break;
+    case 12: launch_lcs_batch<12>(st, count, a); break;
+    case 13: launch_lcs_batch<13>(st, count, a); break;
+    case 14: launch_lcs_batch<14>(st, count, a); break;
+    case 15: launch_lcs_batch<15>(st, count, a); break;
+    default: launch_lcs_batch<16>(st, count, a); break;
+  }
+}
+
 void launch_batch_k(int K, hipStream_t st, int count, int alpha, const BatchArgs& a, bool trace = false) {
   switch (K) {
     case 1: launch_batch<1>(st, count, alpha, a, trace); break;
@@ -1059,6 +1085,11 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
   }
   if (n_pairs < 0 || (n_pairs > 0 && (!seqs || !off_x || !len_x || !off_y || !len_y || !score || !end_i || !end_j)))
     return fail(ctx, SA_ERR_ARG, "bad batch arguments");
+  const bool lcs = al && al->kind == KIND_LCS;  // raw byte equality: no scoring scheme
+  static const int8_t kNoSub[1] = {0};
+  static const uint8_t kNoMap[256] = {0};
+  static const sa_scoring kNoScoring{0.0, 0.0, kNoSub, 1, kNoMap};
+  if (lcs) sc = &kNoScoring;
   if (!sc || !sc->sub || !sc->idx256 || sc->alpha < 1 || sc->alpha > 31) return fail(ctx, SA_ERR_ARG, "bad scoring");
   if (sc->gap_open != std::floor(sc->gap_open) || sc->gap_extend != std::floor(sc->gap_extend))
     return fail(ctx, SA_ERR_UNSUPPORTED, "fractional gap penalties are not implemented on the batch path");
@@ -1108,7 +1139,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     if (len_x[k] == 0 || len_y[k] == 0) {
       score[k] = 0;
       end_i[k] = end_j[k] = 0;
-      if (al && al->kind == KIND_NW) empty_side.push_back(k);  // a border walk (main.cpp: row 0 / column 0)
+      if (al && al->kind != KIND_SW) empty_side.push_back(k);  // a border walk (main.cpp: row 0 / column 0)
     } else if (len_x[k] > kBatchMaxM || len_y[k] > kBatchMaxN - 200) {
       slow.push_back(k);
     } else {
@@ -1212,7 +1243,9 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
         int CB = 8;
         while ((1 << CB) < group_nmax[K] + 160) ++CB;
         a.CB = CB;
-        if (al && al->kind == KIND_NW)
+        if (lcs)
+          launch_lcs_batch_k(K, st, a.n_desc, a);
+        else if (al && al->kind == KIND_NW)
           launch_nw_batch_k(K, st, a.n_desc, alpha, a);
         else
           launch_batch_k(K, st, a.n_desc, alpha, a, al != nullptr);
@@ -1220,7 +1253,9 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
       if (al) {
         a.desc = (const PairDesc*)ctx->b_desc.p + ch.lo;
         a.n_desc = (int)(ch.hi - ch.lo);
-        if (al->kind == KIND_NW)
+        if (lcs)
+          hipLaunchKernelGGL(lcs_batch_traceback, dim3((a.n_desc + 63) / 64), dim3(64), 0, st, a);
+        else if (al->kind == KIND_NW)
           hipLaunchKernelGGL(nw_batch_traceback, dim3((a.n_desc + 63) / 64), dim3(64), 0, st, a);
         else
           hipLaunchKernelGGL(sw_batch_traceback, dim3((a.n_desc + 63) / 64), dim3(64), 0, st, a);
@@ -1281,9 +1316,9 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
   }
   for (int64_t k : empty_side) {  // global alignment against nothing: the reference's border chain and walk
     std::vector<int> rowb, colb;
-    border_chains(KIND_NW, len_x[k], len_y[k], sc, rowb, colb);
+    border_chains(al->kind, len_x[k], len_y[k], sc, rowb, colb);
     sa_result r{};
-    border_only_result(KIND_NW, len_x[k], len_y[k], rowb, colb, &r);
+    border_only_result(al->kind, len_x[k], len_y[k], rowb, colb, &r);
     score[k] = (int32_t)r.score;
     end_i[k] = len_x[k];
     end_j[k] = len_y[k];
@@ -1451,6 +1486,16 @@ int sa_sw_batch_align(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, co
                       uint8_t** ops_pool, int64_t* ops_pool_bytes, float* kernel_ms) {
   const BatchAlign al{KIND_SW, start_i, start_j, ops_off, n_ops, ops_pool, ops_pool_bytes};
   return run_batch(ctx, seqs, off_x, len_x, off_y, len_y, n_pairs, sc, score, end_i, end_j, kernel_ms, &al);
+}
+
+int sa_lcs_batch_align(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x, const int64_t* off_y,
+                       const int32_t* len_y, int64_t n_pairs, int32_t* score, int64_t* ops_off, int32_t* n_ops,
+                       uint8_t** ops_pool, int64_t* ops_pool_bytes, float* kernel_ms) {
+  if (!ctx) return SA_ERR_ARG;
+  if (n_pairs < 0 || (n_pairs > 0 && !score)) return fail(ctx, SA_ERR_ARG, "bad batch arguments");
+  std::vector<int32_t> ei((size_t)std::max<int64_t>(n_pairs, 1)), ej((size_t)std::max<int64_t>(n_pairs, 1));
+  const BatchAlign al{KIND_LCS, nullptr, nullptr, ops_off, n_ops, ops_pool, ops_pool_bytes};
+  return run_batch(ctx, seqs, off_x, len_x, off_y, len_y, n_pairs, nullptr, score, ei.data(), ej.data(), kernel_ms, &al);
 }
 
 int sa_nw_batch_align(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x, const int64_t* off_y,

@@ -157,6 +157,9 @@ def load_library() -> C.CDLL:
     L.sa_nw_batch_align.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, C.POINTER(_Scoring), vp, vp, vp, C.POINTER(vp),
                                     C.POINTER(C.c_int64), C.POINTER(C.c_float)]
     L.sa_nw_batch_align.restype = C.c_int
+    L.sa_lcs_batch_align.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_int64),
+                                     C.POINTER(C.c_float)]
+    L.sa_lcs_batch_align.restype = C.c_int
     L.sa_free_pool.argtypes = [vp]
     L.sa_free_pool.restype = None
     for f in ("sa_set_stream", "sa_set_tuning", "sa_release_workspace", "sa_nw", "sa_sw", "sa_lcs", "sa_sw_batch",
@@ -370,6 +373,35 @@ class Engine:
                                         nops.ctypes.data, C.byref(pool), C.byref(pool_bytes), C.byref(ms))
         del keep
         if rc and rc != SA_ERR_INVALID_CODE:
+            raise SeqAlignError(rc, self.lib.sa_last_error(self.ctx).decode())
+        z = np.zeros(n, np.int32)
+        out = BatchAlignment(score, len_x.copy(), len_y.copy(), z, z.copy(), ops_off, nops, np.zeros(0, np.uint8), ms.value, rc)
+        nb = int(pool_bytes.value)
+        if nb:
+            out.ops_pool = np.ctypeslib.as_array(C.cast(pool, C.POINTER(C.c_uint8)), shape=(nb,))
+            out._release = (self.lib.sa_free_pool, pool)
+        else:
+            self.lib.sa_free_pool(pool)
+        return out
+
+
+    def lcs_batch_align(self, seqs, off_x, len_x, off_y, len_y):
+        """LCS of many pairs with their tracebacks (sa_lcs_batch_align)."""
+        seqs = _u8(seqs)
+        off_x = np.ascontiguousarray(off_x, np.int64)
+        off_y = np.ascontiguousarray(off_y, np.int64)
+        len_x = np.ascontiguousarray(len_x, np.int32)
+        len_y = np.ascontiguousarray(len_y, np.int32)
+        n = len(off_x)
+        score, nops = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        ops_off = np.zeros(n, np.int64)
+        ms = C.c_float(0)
+        pool = C.c_void_p()
+        pool_bytes = C.c_int64(0)
+        rc = self.lib.sa_lcs_batch_align(self.ctx, seqs.ctypes.data, off_x.ctypes.data, len_x.ctypes.data, off_y.ctypes.data,
+                                         len_y.ctypes.data, n, score.ctypes.data, ops_off.ctypes.data, nops.ctypes.data,
+                                         C.byref(pool), C.byref(pool_bytes), C.byref(ms))
+        if rc:
             raise SeqAlignError(rc, self.lib.sa_last_error(self.ctx).decode())
         z = np.zeros(n, np.int32)
         out = BatchAlignment(score, len_x.copy(), len_y.copy(), z, z.copy(), ops_off, nops, np.zeros(0, np.uint8), ms.value, rc)

@@ -214,3 +214,43 @@ def test_nw_batch_align_seed_segments(engine):
                 if c["s1"] and c["s2"]:
                     assert int(b.score[k]) == c["score"], c
                 assert replay(c["s1"].encode("latin-1"), c["s2"].encode("latin-1"), b.ops(k)) == (c["a1"], c["a2"]), c
+
+
+# ---- sa_lcs_batch_align ----
+def test_lcs_batch_align(engine, oracle):
+    rng = np.random.default_rng(31)
+    lens = [(m, int(rng.integers(1, 500))) for m in list(range(1, 70, 3)) + list(range(120, 1030, 61)) + [63, 64, 65, 127, 128, 129, 1023, 1024]]
+    lens += [(int(rng.integers(1, 400)), n) for n in (1, 2, 15, 16, 17, 63, 64, 65, 127, 128, 129)]
+    for alphabet, related in (("ACGT", True), (PROT20, True), ("AB", False), ("A", False)):
+        pool, ox, lx, oy, ly = make_pool(rng, lens, alphabet, related=related)
+        b = engine.lcs_batch_align(pool, ox, lx, oy, ly)
+        for k in range(len(ox)):
+            w = oracle.lcs(pool[ox[k]:ox[k] + lx[k]], pool[oy[k]:oy[k] + ly[k]])
+            assert int(b.score[k]) == w.score, (alphabet, k, lx[k], ly[k])
+            assert np.array_equal(b.ops(k), w.ops), (alphabet, k, lx[k], ly[k])
+    # empty sides and a pair beyond the batch kernel's limits
+    pool = np.frombuffer(b"ACGTACGT" + b"ACGT" * 300 + b"ACGTT" * 260, np.uint8)
+    ox, lx = np.array([0, 0, 0, 8]), np.array([8, 0, 0, 1200], np.int32)
+    oy, ly = np.array([0, 0, 0, 8 + 1200]), np.array([0, 5, 0, 1300], np.int32)
+    b = engine.lcs_batch_align(pool, ox, lx, oy, ly)
+    for k in range(4):
+        w = oracle.lcs(pool[ox[k]:ox[k] + lx[k]], pool[oy[k]:oy[k] + ly[k]])
+        assert int(b.score[k]) == w.score and np.array_equal(b.ops(k), w.ops), k
+
+
+def test_lcs_batch_align_seed_segments(engine):
+    from seed_common import load, replay
+
+    cases = [c for c in load()["lcs"] if c["s1"] or c["s2"]]
+    pool, ox, lx, oy, ly, pos = [], [], [], [], [], 0
+    for c in cases:
+        for s, o, l in ((c["s1"], ox, lx), (c["s2"], oy, ly)):
+            o.append(pos)
+            l.append(len(s))
+            pool.append(s)
+            pos += len(s)
+    buf = np.frombuffer("".join(pool).encode("latin-1"), np.uint8)
+    b = engine.lcs_batch_align(buf, np.array(ox), np.array(lx, np.int32), np.array(oy), np.array(ly, np.int32))
+    for k, c in enumerate(cases):
+        assert int(b.score[k]) == c["len"], c
+        assert replay(c["s1"].encode("latin-1"), c["s2"].encode("latin-1"), b.ops(k)) == (c["g1"], c["g2"]), c
