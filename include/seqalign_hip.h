@@ -167,6 +167,21 @@ int sa_lcs_batch_align(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, c
                        int64_t* ops_off, int32_t* n_ops, uint8_t** ops_pool, int64_t* ops_pool_bytes,
                        float* kernel_ms);
 
+/* Many windows, the seed_aligner's windowed local alignment: perform_sw_in_window (main_fmindex.cpp:938-1047)
+ * per pair, x = the query, y = the reference window.  Its fill is localalign()'s (same floors, same first
+ * strict row-major maximum); its traceback is a three-state machine that, as written, starts in the match
+ * state at the best cell and re-enters the match state after each diagonal step, so with a negative
+ * gap-open penalty (required here; SA_ERR_UNSUPPORTED otherwise) the alignment it returns is the
+ * UNGAPPED diagonal through the best cell for as long as S > 0: x[start_i .. end_i) against
+ * y[start_j .. end_j), aligned_len = end_i - start_i = end_j - start_j (0 and all-zero cells when the
+ * score is 0).  The reference's query_start / target_start are q_offset + start_i / t_offset + start_j
+ * and its *_end are q_offset + end_i - 1 / t_offset + end_j - 1.  Windows are limited to the batch
+ * kernels' 1024 x 3895 (SA_ERR_UNSUPPORTED beyond).  Invalid residues as sa_sw_batch. */
+int sa_sw_window_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x,
+                       const int64_t* off_y, const int32_t* len_y, int64_t n_pairs, const sa_scoring* sc,
+                       int32_t* score, int32_t* end_i, int32_t* end_j, int32_t* start_i, int32_t* start_j,
+                       int32_t* aligned_len, float* kernel_ms);
+
 /* ---- one long pair over several GPUs: column stripes ----
  *
  * Replaces the reference's MPI row-block chain (main.cpp:1050-1147, 1151-1177), which is serial;

@@ -665,6 +665,38 @@ __global__ void sw_batch_traceback(const BatchArgs a) {
   a.start_j[pd.idx] = sc > 0 ? j : 0;
 }
 
+// The seed_aligner's perform_sw_in_window traceback (main_fmindex.cpp:989-1030) for negative gap-open
+// penalties: its state machine starts in the match state at the best cell (a cell that ends a gap cannot
+// be the maximum) and, as written, re-enters the match state after every diagonal move, so the
+// "alignment" is the ungapped diagonal through the best cell for as long as S > 0 -- and S > 0 is
+// exactly "the stored code is not the zero-cell tag 3".  One thread per window counts those steps.
+__global__ void sw_batch_diag_walk(const BatchArgs a) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.n_desc) return;
+  const PairDesc pd = a.desc[q];
+  const int K = (pd.m + 63) / 64;
+  int i = a.end_i[pd.idx], j = a.end_j[pd.idx];
+  const int sc = a.score[pd.idx];
+  const uint32_t* tr = a.trace + pd.off_trace;
+  int len = 0;
+  if (sc > 0) {
+    while (i > 0 && j > 0) {
+      const int r = i - 1, c = j - 1;
+      const int l = r / K, k = r - l * K;
+      const int t = c + l;
+      if (((tr[((size_t)(t >> 4) * 64 + l) * K + k] >> (2 * (t & 15))) & 3u) == 3u) break;
+      ++len;
+      --i;
+      --j;
+    }
+  } else {
+    i = j = 0;
+  }
+  a.n_ops[pd.idx] = len;
+  a.start_i[pd.idx] = sc > 0 ? i : 0;
+  a.start_j[pd.idx] = sc > 0 ? j : 0;
+}
+
 template <int K>
 inline size_t batch_lds_bytes(int alpha) {
   return (size_t)(alpha + 1) * 64 * BatchGeo<K>::PW * 4 + (kBatchMaxN + 256) + 256 + (size_t)alpha * alpha + 16;

@@ -1066,6 +1066,7 @@ struct BatchAlign {
   int32_t* n_ops;
   uint8_t** pool;
   int64_t* pool_bytes;
+  int diag_only = 0;  // KIND_SW: the seed_aligner's window traceback (ungapped diagonal while S > 0): n_ops = its length, no op pool
 };
 
 // Many independent pairs: one wavefront per pair (sa_batch.h).  Pairs the fast kernel does not
@@ -1078,9 +1079,11 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
   if (!ctx) return SA_ERR_ARG;
   if (kernel_ms) *kernel_ms = 0.f;
   if (al) {
-    if ((al->kind == KIND_SW && (!al->start_i || !al->start_j)) || !al->ops_off || !al->n_ops || !al->pool)
+    if ((al->kind == KIND_SW && (!al->start_i || !al->start_j)) || !al->n_ops || (!al->diag_only && (!al->ops_off || !al->pool)))
       return fail(ctx, SA_ERR_ARG, "bad batch arguments");
-    *al->pool = nullptr;
+    if (al->diag_only && sc && !(sc->gap_open < 0))
+      return fail(ctx, SA_ERR_UNSUPPORTED, "the window traceback is the ungapped diagonal only for a negative gap-open penalty");
+    if (al->pool) *al->pool = nullptr;
     if (al->pool_bytes) *al->pool_bytes = 0;
   }
   if (n_pairs < 0 || (n_pairs > 0 && (!seqs || !off_x || !len_x || !off_y || !len_y || !score || !end_i || !end_j)))
@@ -1107,20 +1110,23 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     if (smax > 31) return fail(ctx, SA_ERR_UNSUPPORTED, "substitution scores beyond +-31 do not fit the int8 tagged profile");
     for (int64_t k = 0; k < n_pairs; ++k) {
       if (len_x[k] < 0 || len_y[k] < 0) return fail(ctx, SA_ERR_ARG, "negative length in pair %lld", (long long)k);
-      al->ops_off[k] = pool_total;
       al->n_ops[k] = 0;
       if (al->start_i) al->start_i[k] = al->start_j[k] = 0;
+      if (al->diag_only) continue;
+      al->ops_off[k] = pool_total;
       pool_total += ((int64_t)len_x[k] + len_y[k] + 3) & ~3LL;
     }
-    *al->pool = pool_acquire((size_t)std::max<int64_t>(pool_total, 4));
-    if (!*al->pool) return fail(ctx, SA_ERR_NOMEM, "host malloc of the %lld-byte op pool failed", (long long)pool_total);
-    if (al->pool_bytes) *al->pool_bytes = pool_total;
+    if (!al->diag_only) {
+      *al->pool = pool_acquire((size_t)std::max<int64_t>(pool_total, 4));
+      if (!*al->pool) return fail(ctx, SA_ERR_NOMEM, "host malloc of the %lld-byte op pool failed", (long long)pool_total);
+      if (al->pool_bytes) *al->pool_bytes = pool_total;
+    }
   }
   struct PoolGuard {  // the pool goes back to the caller only with SA_OK / SA_ERR_INVALID_CODE
     const BatchAlign* al;
     bool keep = false;
     ~PoolGuard() {
-      if (al && !keep && *al->pool) {
+      if (al && al->pool && !keep && *al->pool) {
         pool_release(*al->pool);
         *al->pool = nullptr;
       }
@@ -1141,6 +1147,9 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
       end_i[k] = end_j[k] = 0;
       if (al && al->kind != KIND_SW) empty_side.push_back(k);  // a border walk (main.cpp: row 0 / column 0)
     } else if (len_x[k] > kBatchMaxM || len_y[k] > kBatchMaxN - 200) {
+      if (al && al->diag_only)
+        return fail(ctx, SA_ERR_UNSUPPORTED, "window %lld (%d x %d) is beyond the batch kernels' %d x %d", (long long)k, len_x[k],
+                    len_y[k], kBatchMaxM, kBatchMaxN - 200);
       slow.push_back(k);
     } else {
       const int K = (len_x[k] + 63) / 64;
@@ -1189,7 +1198,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
           c = Chunk{q, q, 0, 0};
         }
         desc[q].off_trace = c.trace_dwords;
-        desc[q].off_ops = al->ops_off[desc[q].idx];
+        desc[q].off_ops = al->diag_only ? 0 : al->ops_off[desc[q].idx];
         c.trace_dwords += td;
         c.ops_bytes += ((long long)desc[q].m + desc[q].n + 3) & ~3LL;
         c.hi = q + 1;
@@ -1257,6 +1266,8 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
           hipLaunchKernelGGL(lcs_batch_traceback, dim3((a.n_desc + 63) / 64), dim3(64), 0, st, a);
         else if (al->kind == KIND_NW)
           hipLaunchKernelGGL(nw_batch_traceback, dim3((a.n_desc + 63) / 64), dim3(64), 0, st, a);
+        else if (al->diag_only)
+          hipLaunchKernelGGL(sw_batch_diag_walk, dim3((a.n_desc + 63) / 64), dim3(64), 0, st, a);
         else
           hipLaunchKernelGGL(sw_batch_traceback, dim3((a.n_desc + 63) / 64), dim3(64), 0, st, a);
       }
@@ -1485,6 +1496,14 @@ int sa_sw_batch_align(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, co
                       int32_t* end_j, int32_t* start_i, int32_t* start_j, int64_t* ops_off, int32_t* n_ops,
                       uint8_t** ops_pool, int64_t* ops_pool_bytes, float* kernel_ms) {
   const BatchAlign al{KIND_SW, start_i, start_j, ops_off, n_ops, ops_pool, ops_pool_bytes};
+  return run_batch(ctx, seqs, off_x, len_x, off_y, len_y, n_pairs, sc, score, end_i, end_j, kernel_ms, &al);
+}
+
+int sa_sw_window_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x, const int64_t* off_y,
+                       const int32_t* len_y, int64_t n_pairs, const sa_scoring* sc, int32_t* score, int32_t* end_i,
+                       int32_t* end_j, int32_t* start_i, int32_t* start_j, int32_t* aligned_len, float* kernel_ms) {
+  BatchAlign al{KIND_SW, start_i, start_j, nullptr, aligned_len, nullptr, nullptr};
+  al.diag_only = 1;
   return run_batch(ctx, seqs, off_x, len_x, off_y, len_y, n_pairs, sc, score, end_i, end_j, kernel_ms, &al);
 }
 

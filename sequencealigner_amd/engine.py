@@ -160,6 +160,9 @@ def load_library() -> C.CDLL:
     L.sa_lcs_batch_align.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, C.POINTER(vp), C.POINTER(C.c_int64),
                                      C.POINTER(C.c_float)]
     L.sa_lcs_batch_align.restype = C.c_int
+    L.sa_sw_window_batch.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, C.POINTER(_Scoring), vp, vp, vp, vp, vp, vp,
+                                     C.POINTER(C.c_float)]
+    L.sa_sw_window_batch.restype = C.c_int
     L.sa_free_pool.argtypes = [vp]
     L.sa_free_pool.restype = None
     for f in ("sa_set_stream", "sa_set_tuning", "sa_release_workspace", "sa_nw", "sa_sw", "sa_lcs", "sa_sw_batch",
@@ -353,6 +356,26 @@ class Engine:
             self.lib.sa_free_pool(pool)
         return out
 
+    def sw_window_batch(self, seqs, off_x, len_x, off_y, len_y, mode="dna", gap_open=-5.0, gap_extend=-1.0, sub=None, idx256=None):
+        """The seed_aligner's windowed SW for many (query, window) pairs (sa_sw_window_batch): returns
+        score, end_i, end_j, start_i, start_j, aligned_len (arrays), kernel ms, rc."""
+        seqs = _u8(seqs)
+        off_x = np.ascontiguousarray(off_x, np.int64)
+        off_y = np.ascontiguousarray(off_y, np.int64)
+        len_x = np.ascontiguousarray(len_x, np.int32)
+        len_y = np.ascontiguousarray(len_y, np.int32)
+        n = len(off_x)
+        i32 = lambda: np.zeros(n, np.int32)  # noqa: E731
+        score, ei, ej, si, sj, ln = i32(), i32(), i32(), i32(), i32(), i32()
+        sc, keep = self._scoring(mode, gap_open, gap_extend, sub, idx256)
+        ms = C.c_float(0)
+        rc = self.lib.sa_sw_window_batch(self.ctx, seqs.ctypes.data, off_x.ctypes.data, len_x.ctypes.data, off_y.ctypes.data,
+                                         len_y.ctypes.data, n, C.byref(sc), score.ctypes.data, ei.ctypes.data, ej.ctypes.data,
+                                         si.ctypes.data, sj.ctypes.data, ln.ctypes.data, C.byref(ms))
+        del keep
+        if rc and rc != SA_ERR_INVALID_CODE:
+            raise SeqAlignError(rc, self.lib.sa_last_error(self.ctx).decode())
+        return score, ei, ej, si, sj, ln, ms.value, rc
 
     def nw_batch_align(self, seqs, off_x, len_x, off_y, len_y, mode="protein", gap_open=-5.0, gap_extend=-1.0, sub=None, idx256=None):
         """Global alignments of many pairs (sa_nw_batch_align): BatchAlignment with end = (m, n), start = (0, 0)."""
