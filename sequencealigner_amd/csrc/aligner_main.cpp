@@ -270,6 +270,17 @@ void run_batch_mode(sa_ctx* ctx, const Options& o) {
   fclose(sum);
 }
 
+// `mpirun -np P ./aligner ...` keeps working: the reference's ranks > 0 only help rank 0 with
+// localalign's rows and otherwise repeat rank 0's work and rewrite its files (main.cpp:1050-1147).
+// Here one process drives the GPU, so a rank > 0 (as the common launchers export it) has nothing to do.
+int launcher_rank() {
+  for (const char* name : {"OMPI_COMM_WORLD_RANK", "PMI_RANK", "PMIX_RANK", "MV2_COMM_WORLD_RANK"}) {
+    const char* v = std::getenv(name);
+    if (v && *v) return std::atoi(v);
+  }
+  return 0;
+}
+
 }  // namespace
 
 int main(int argc, char** argv) {
@@ -324,6 +335,7 @@ int main(int argc, char** argv) {
       std::cerr << "Missing required arguments: --query, --target, --choice\n";
       return 1;
     }
+    if (launcher_rank() > 0) return 0;
     std::filesystem::create_directories(o.outdir);
     if (o.batch && o.choice >= 1 && o.choice <= 4) {
       ctx = sa_create(o.device);

@@ -93,3 +93,20 @@ def test_multi_fasta_records(tmp_path):
     assert read_fasta_records(g) == [("", b"ACGTAC"), ("z", b"G")]
     with pytest.raises(FileNotFoundError):
         read_fasta_records(tmp_path / "missing.fa")
+
+
+def test_cli_under_mpirun_ranks_above_zero_do_nothing(tmp_path):
+    """existing `mpirun -np P ./aligner ...` scripts keep working -- only rank 0 runs the GPU job."""
+    import os
+
+    q = tmp_path / "q.fa"
+    q.write_text(">q\nACGT\n")
+    out = tmp_path / "o"
+    for var in ("OMPI_COMM_WORLD_RANK", "PMI_RANK"):
+        env = dict(os.environ, **{var: "3"})
+        r = subprocess.run([str(PKG / "aligner"), "--query", str(q), "--target", str(q), "--choice", "1", "--outdir", str(out)],
+                           capture_output=True, text=True, timeout=60, env=env)
+        assert r.returncode == 0 and r.stdout == "" and r.stderr == "" and not out.exists()
+    env = dict(os.environ, OMPI_COMM_WORLD_RANK="1")  # argument errors stay per-rank, as in the reference
+    r = subprocess.run([str(PKG / "aligner"), "--bogus"], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 1
