@@ -132,6 +132,14 @@ int sa_sw_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const in
                 const sa_scoring* sc, int32_t* score, int32_t* end_i, int32_t* end_j,
                 float* kernel_ms);
 
+/* Sequence pool already in device memory (a caller that produced or staged the sequences on the GPU, e.g. a
+ * torch tensor): while a pool is set, every batch entry point below reads pair k at d_seqs + off_x[k] /
+ * off_y[k], ignores its `seqs` argument (NULL is fine) and copies nothing host -> device but the pair
+ * descriptors.  The memory stays the caller's and must stay valid and unchanged during those calls; work queued
+ * on other streams that writes it must have completed.  d_seqs = NULL returns to host pools.  No counterpart in
+ * the reference (extension of the config-5 workload). */
+int sa_batch_set_device_pool(sa_ctx* ctx, const uint8_t* d_seqs, int64_t bytes);
+
 /* Many independent pairs with their full local alignments: per pair what sa_sw returns (score, end
  * cell, the 'X' cell where the traceback stopped, the op list end -> start).  The reference has no
  * batch mode -- it aligns one pair per process (processFasta reads one record, main.cpp:290-308) --

@@ -47,6 +47,8 @@ struct sa_ctx {
   Buf xenc, yenc, prof, sub, colb, bot, state, trace, rowbest, small, ops;
   // batch workspaces
   Buf b_seq, b_desc, b_out;
+  const uint8_t* dev_pool = nullptr;  // sa_batch_set_device_pool: the batch entry points read the sequences here
+  int64_t dev_pool_bytes = 0;
   Buf lbuf, dpbuf, pbuf;
   // geometry of the last fill, for the traceback that follows it
   struct {
@@ -1086,7 +1088,8 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     if (al->pool) *al->pool = nullptr;
     if (al->pool_bytes) *al->pool_bytes = 0;
   }
-  if (n_pairs < 0 || (n_pairs > 0 && (!seqs || !off_x || !len_x || !off_y || !len_y || !score || !end_i || !end_j)))
+  const bool resident = ctx->dev_pool != nullptr;
+  if (n_pairs < 0 || (n_pairs > 0 && ((!seqs && !resident) || !off_x || !len_x || !off_y || !len_y || !score || !end_i || !end_j)))
     return fail(ctx, SA_ERR_ARG, "bad batch arguments");
   const bool lcs = al && al->kind == KIND_LCS;  // raw byte equality: no scoring scheme
   static const int8_t kNoSub[1] = {0};
@@ -1176,8 +1179,10 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
 
   int rc = SA_OK;
   int h_err = 0;
+  if (resident && pool_end > ctx->dev_pool_bytes)
+    return fail(ctx, SA_ERR_ARG, "a pair ends at byte %lld of a %lld-byte device pool", (long long)pool_end, (long long)ctx->dev_pool_bytes);
   if (!desc.empty()) {
-    if ((rc = ensure(ctx, ctx->b_seq, (size_t)pool_end + 64))) return rc;
+    if (!resident && (rc = ensure(ctx, ctx->b_seq, (size_t)pool_end + 64))) return rc;
     if ((rc = ensure(ctx, ctx->b_desc, desc.size() * sizeof(PairDesc)))) return rc;
     if ((rc = ensure(ctx, ctx->b_out, (size_t)n_pairs * 24 + 1024 + 2048))) return rc;
     // aligning variant: cut the (K-sorted) pair list into chunks whose codes fit the trace budget
@@ -1209,7 +1214,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
       if ((rc = ensure(ctx, ctx->trace, (size_t)tmax * 4))) return rc;
       if ((rc = ensure(ctx, ctx->ops, (size_t)pool_total + 64))) return rc;
     }
-    HIPCK(ctx, hipMemcpyAsync(ctx->b_seq.p, seqs, (size_t)pool_end, hipMemcpyHostToDevice, st));
+    if (!resident) HIPCK(ctx, hipMemcpyAsync(ctx->b_seq.p, seqs, (size_t)pool_end, hipMemcpyHostToDevice, st));
     HIPCK(ctx, hipMemcpyAsync(ctx->b_desc.p, desc.data(), desc.size() * sizeof(PairDesc), hipMemcpyHostToDevice, st));
     int* d_score = (int*)ctx->b_out.p;
     int* d_ei = d_score + n_pairs;
@@ -1224,7 +1229,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     HIPCK(ctx, hipMemcpyAsync(d_sub, sc->sub, (size_t)alpha * alpha, hipMemcpyHostToDevice, st));
     HIPCK(ctx, hipMemcpyAsync(d_map, sc->idx256, 256, hipMemcpyHostToDevice, st));
     BatchArgs a{};
-    a.seqs = (const uint8_t*)ctx->b_seq.p;
+    a.seqs = resident ? ctx->dev_pool : (const uint8_t*)ctx->b_seq.p;
     a.sub = d_sub;
     a.idx256 = d_map;
     a.alpha = alpha;
@@ -1299,9 +1304,19 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
       }
     }
   }
+  std::vector<uint8_t> hx, hy;  // a resident pool: the single-pair path takes host buffers
   for (int64_t k : slow) {
     sa_result r;
-    const int rc1 = run_pair(ctx, al ? al->kind : KIND_SW, seqs + off_x[k], len_x[k], seqs + off_y[k], len_y[k], sc,
+    const uint8_t *px = seqs + off_x[k], *py = seqs + off_y[k];
+    if (resident) {
+      hx.resize((size_t)len_x[k]);
+      hy.resize((size_t)len_y[k]);
+      HIPCK(ctx, hipMemcpy(hx.data(), ctx->dev_pool + off_x[k], hx.size(), hipMemcpyDeviceToHost));
+      HIPCK(ctx, hipMemcpy(hy.data(), ctx->dev_pool + off_y[k], hy.size(), hipMemcpyDeviceToHost));
+      px = hx.data();
+      py = hy.data();
+    }
+    const int rc1 = run_pair(ctx, al ? al->kind : KIND_SW, px, len_x[k], py, len_y[k], sc,
                              al ? 0 : SA_FLAG_NO_TRACEBACK, &r);
     if (rc1 == SA_OK) {
       score[k] = (int32_t)r.score;
@@ -1483,6 +1498,16 @@ int sa_stripe_fill(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m, const uin
 
 int sa_stripe_traceback(sa_ctx* ctx, int64_t start_i, int64_t start_j, sa_result* out) {
   return run_stripe_traceback(ctx, start_i, start_j, out);
+}
+
+int sa_batch_set_device_pool(sa_ctx* ctx, const uint8_t* d_seqs, int64_t bytes) {
+  if (!ctx) return SA_ERR_ARG;
+  if (d_seqs && bytes <= 0) return fail(ctx, SA_ERR_ARG, "a device pool needs a positive size");
+  // no hipPointerGetAttributes check: the pool may have been allocated through another HIP runtime instance in
+  // this process (PyTorch ships its own), which this one cannot look up although the GPU address space is shared
+  ctx->dev_pool = d_seqs;
+  ctx->dev_pool_bytes = d_seqs ? bytes : 0;
+  return SA_OK;
 }
 
 int sa_sw_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x, const int64_t* off_y,

@@ -163,6 +163,8 @@ def load_library() -> C.CDLL:
     L.sa_sw_window_batch.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, C.POINTER(_Scoring), vp, vp, vp, vp, vp, vp,
                                      C.POINTER(C.c_float)]
     L.sa_sw_window_batch.restype = C.c_int
+    L.sa_batch_set_device_pool.argtypes = [vp, vp, C.c_int64]
+    L.sa_batch_set_device_pool.restype = C.c_int
     L.sa_free_pool.argtypes = [vp]
     L.sa_free_pool.restype = None
     for f in ("sa_set_stream", "sa_set_tuning", "sa_release_workspace", "sa_nw", "sa_sw", "sa_lcs", "sa_sw_batch",
@@ -173,6 +175,8 @@ def load_library() -> C.CDLL:
 
 
 def _u8(b) -> np.ndarray:
+    if b is None:  # batch calls with a device-resident pool
+        return np.zeros(1, dtype=np.uint8)
     if isinstance(b, str):
         b = b.encode("latin-1")
     if isinstance(b, (bytes, bytearray)):
@@ -304,6 +308,13 @@ class Engine:
         if rc:
             raise self._err(rc, r)
         return self._wrap(r, 0, 0, False)
+
+    def set_device_pool(self, data_ptr, nbytes):
+        """The batch calls read their sequences from this device buffer (e.g. tensor.data_ptr(), tensor.numel())
+        instead of copying the host pool in; set_device_pool(None, 0) switches back."""
+        rc = self.lib.sa_batch_set_device_pool(self.ctx, data_ptr, int(nbytes))
+        if rc:
+            raise SeqAlignError(rc, self.lib.sa_last_error(self.ctx).decode())
 
     def sw_batch(self, seqs, off_x, len_x, off_y, len_y, mode="protein", gap_open=-5.0, gap_extend=-1.0, sub=None, idx256=None):
         seqs = _u8(seqs)

@@ -254,3 +254,48 @@ def test_lcs_batch_align_seed_segments(engine):
     for k, c in enumerate(cases):
         assert int(b.score[k]) == c["len"], c
         assert replay(c["s1"].encode("latin-1"), c["s2"].encode("latin-1"), b.ops(k)) == (c["g1"], c["g2"]), c
+
+
+# ---- sa_batch_set_device_pool: sequences already on the GPU ----
+def test_device_resident_pool_gives_identical_results(engine):
+    import ctypes as C
+
+    import sequencealigner_amd as sa
+
+    rng = np.random.default_rng(31)
+    lens = [(int(rng.integers(1, 900)), int(rng.integers(1, 900))) for _ in range(80)] + [(1100, 500), (0, 40), (40, 0), (64, 64)]
+    pool, ox, lx, oy, ly = make_pool(rng, lens, related=True)
+    host = {
+        "sw": engine.sw_batch(pool, ox, lx, oy, ly, "protein"),
+        "swa": engine.sw_batch_align(pool, ox, lx, oy, ly, "protein"),
+        "nwa": engine.nw_batch_align(pool, ox, lx, oy, ly, "protein"),
+        "lcs": engine.lcs_batch_align(pool, ox, lx, oy, ly),
+    }
+    # device memory through the HIP runtime the library itself is linked to (torch must not be imported AFTER the
+    # library has initialised HIP: INTEGRATION.md, "Other hosts")
+    hip = C.CDLL("libamdhip64.so.7")
+    dev = C.c_void_p()
+    assert hip.hipMalloc(C.byref(dev), C.c_size_t(len(pool))) == 0
+    assert hip.hipMemcpy(dev, C.c_void_p(pool.ctypes.data), C.c_size_t(len(pool)), 1) == 0  # hipMemcpyHostToDevice
+    engine.set_device_pool(dev.value, len(pool))
+    try:
+        sc, ei, ej, _ms, rc = engine.sw_batch(None, ox, lx, oy, ly, "protein")
+        assert rc == 0 and all(np.array_equal(a, b) for a, b in zip((sc, ei, ej), host["sw"][:3]))
+        for key, call in (("swa", lambda: engine.sw_batch_align(None, ox, lx, oy, ly, "protein")),
+                          ("nwa", lambda: engine.nw_batch_align(None, ox, lx, oy, ly, "protein")),
+                          ("lcs", lambda: engine.lcs_batch_align(None, ox, lx, oy, ly))):
+            b, h = call(), host[key]
+            for f in ("score", "end_i", "end_j", "start_i", "start_j", "n_ops", "ops_off"):
+                assert np.array_equal(getattr(b, f), getattr(h, f)), (key, f)
+            for k in range(len(ox)):
+                assert np.array_equal(b.ops(k), h.ops(k)), (key, k)
+        # a pair that ends beyond the pool is refused
+        with pytest.raises(sa.engine.SeqAlignError):
+            engine.sw_batch(None, ox + 10 ** 9, lx, oy, ly, "protein")
+    finally:
+        engine.set_device_pool(None, 0)
+        hip.hipFree(dev)
+    sc2 = engine.sw_batch(pool, ox, lx, oy, ly, "protein")[0]
+    assert np.array_equal(sc2, host["sw"][0])
+    with pytest.raises(sa.engine.SeqAlignError):  # a pool needs a size
+        engine.set_device_pool(1234, 0)
