@@ -56,6 +56,24 @@ struct BatchArgs {
 
 constexpr int kBatchMaxN = 4095;  // LDS room for the encoded target; the host admits n <= kBatchMaxN - 200
 constexpr int kBatchMaxM = 1024;  // 64 lanes x 16 rows
+constexpr int kBatchCB = 13;      // column bits of the first-maximum key (2^13 > kBatchMaxN + 128)
+
+// (v << SH) + c as ONE instruction.  Written in C the compiler rebuilds c (a per-step counter) from its loop
+// invariants and emits a shift plus a three-operand add per cell.
+template <int SH>
+__device__ __forceinline__ uint32_t shl_add(uint32_t v, uint32_t c) {
+  uint32_t r;
+  asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "n"(SH), "v"(c));
+  return r;
+}
+
+// max of three as ONE v_max3_i32.  e and f are known to be non-negative, so the compiler turns the outer signed
+// max into an unsigned one and then cannot fuse the two into a max3.
+__device__ __forceinline__ int max3_i32(int x, int y, int z) {
+  int r;
+  asm("v_max3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
+  return r;
+}
 
 template <int K>
 struct BatchGeo {
@@ -127,7 +145,11 @@ __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
   __syncthreads();
 
   const char* ldsLane = reinterpret_cast<const char*>(prof) + lane * 4 * G::PW;
-  const int go = TRACE ? 4 * a.go : a.go, ge = TRACE ? 4 * a.ge : a.ge, CB = a.CB;
+  const int go = TRACE ? 4 * a.go : a.go, ge = TRACE ? 4 * a.ge : a.ge;
+  // Column bits of the tracking key: a compile-time constant, so that the key is ONE v_lshl_add_u32 per cell
+  // (as a launch argument it cost a shift and a three-operand add).  n + 63 + 64 < 2^13 (kBatchMaxN), and
+  // 19 bits of score hold 127 x 1024.
+  constexpr int CB = kBatchCB;
   int H[K], E[K];
   uint32_t bk[K];
 #pragma unroll
@@ -164,8 +186,10 @@ __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
   yb = (int)yenc[lane] * G::ROWB;
   int yv = dpp_shr1(yb, ypass);
   yb = dpp_shl1(yb, yb);
-  uint32_t pw[G::PW];
-  load_prof(yv, pw);
+  // two profile buffers used alternately (16 steps: back at buffer 0 when the loop comes round): a single
+  // buffer refilled through a copy costs PW moves per step
+  uint32_t pwb[2][G::PW];
+  load_prof(yv, pwb[0]);
 
 #pragma unroll 1
   for (int t0 = 0; t0 < nsteps; t0 += 16) {
@@ -178,15 +202,15 @@ __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
     for (int u = 0; u < 16; ++u) {
       const int t = t0 + u;
       // hand-off from the lane above (values of the previous step); lane 0 sees the zero border
-      int up = dpp_shr1(0, passH);
-      int uf = dpp_shr1(0, passF);
+      int up = dpp_shr1_zero(passH);
+      int uf = dpp_shr1_zero(passF);
       // next step's symbol and profile word
       if (u == 15 && ((t0 + 16) & 63) == 0) yb = (int)yenc[t + 1 + lane] * G::ROWB;
       ypass = yv;
       const int yv_next = dpp_shr1(yb, ypass);
-      yb = dpp_shl1(yb, yb);
-      uint32_t pw_next[G::PW];
-      load_prof(yv_next, pw_next);
+      yb = dpp_shl1_any(yb);  // lane 63 is reloaded before it matters
+      const uint32_t (&pw)[G::PW] = pwb[u & 1];
+      load_prof(yv_next, pwb[(u & 1) ^ 1]);
 
       int diag = dprev;
       dprev = up;
@@ -198,16 +222,20 @@ __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
         if (TRACE) {
           f = max(max(up + go, uf + ge), 0);            // tag 0
           e = max(max(left + go + 1, E[k] + ge), 1);    // tag 1
-          const int mv = max(diag + sg, 2);             // tag 2
-          const int ht = max(max(max(mv, e), f), 3);    // a zero cell wins with tag 3 = 'X'
+          // M needs no floor of its own: it only feeds the cell maximum, where the 'X' floor (tag 3 beats
+          // every tagged value <= 2) subsumes it
+          const int ht = max(max3_i32(diag + sg, e, f), 3);  // a zero cell wins with tag 3 = 'X'
           tacc[k] = __builtin_amdgcn_alignbit((uint32_t)ht, tacc[k], 2);
+          // pack here and now: left alone the compiler sinks the packing to the end of the sub-block and parks
+          // every cell's maximum in an AGPR until then
+          asm volatile("" : "+v"(tacc[k]));
           h = ht & ~3;
-          bk[k] = max(bk[k], ((uint32_t)h << (CB - 2)) + (uint32_t)cinv);
+          bk[k] = max(bk[k], shl_add<CB - 2>((uint32_t)h, (uint32_t)cinv));
         } else {
           f = max(max(up + go, uf + ge), 0);
           e = max(max(left + go, E[k] + ge), 0);
-          h = max(max(diag + sg, e), f);
-          bk[k] = max(bk[k], ((uint32_t)h << CB) + (uint32_t)cinv);
+          h = max3_i32(diag + sg, e, f);
+          bk[k] = max(bk[k], shl_add<CB>((uint32_t)h, (uint32_t)cinv));
         }
         E[k] = e;
         diag = left;
@@ -219,8 +247,6 @@ __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
       passF = uf;
       --cinv;
       yv = yv_next;
-#pragma unroll
-      for (int i = 0; i < G::PW; ++i) pw[i] = pw_next[i];
     }
     if (TRACE) {
 #pragma unroll
@@ -280,13 +306,18 @@ __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
 template <int K, bool MASK>
 __device__ __forceinline__ void nw_batch_steps(int t0, int lane, int n, int go, int ge, const char* ldsLane, const uint8_t* yenc,
                                                int (&H)[K], int (&E)[K], int& passH, int& passF, int& dprev, int& ypass, int& yb,
-                                               int& yv, uint32_t (&pw)[BatchGeo<K>::PW], uint32_t* tdst) {
+                                               int& yv, uint32_t (&pw_io)[BatchGeo<K>::PW], uint32_t* tdst) {
   using G = BatchGeo<K>;
   uint32_t tacc[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) tacc[k] = 0;
+  uint32_t pwb[2][G::PW];  // two profile buffers used alternately: no copy per step
+#pragma unroll
+  for (int i = 0; i < G::PW; ++i) pwb[0][i] = pw_io[i];
 #pragma unroll
   for (int u = 0; u < 16; ++u) {
+    const uint32_t (&pw)[G::PW] = pwb[u & 1];
+    uint32_t (&pw_next)[G::PW] = pwb[(u & 1) ^ 1];
     const int t = t0 + u;
     // lane 0 sits under row 0 of the matrix: H[0][t+1] = go + t ge (tag-free), F[0][.] = -inf
     int up = dpp_shr1(go + t * ge, passH);
@@ -294,8 +325,7 @@ __device__ __forceinline__ void nw_batch_steps(int t0, int lane, int n, int go, 
     if (u == 15 && ((t0 + 16) & 63) == 0) yb = (int)yenc[t + 1 + lane] * G::ROWB;
     ypass = yv;
     const int yv_next = dpp_shr1(yb, ypass);
-    yb = dpp_shl1(yb, yb);
-    uint32_t pw_next[G::PW];
+    yb = dpp_shl1_any(yb);  // lane 63 is reloaded before it matters
     if (G::PW == 1) {
       pw_next[0] = *reinterpret_cast<const uint32_t*>(ldsLane + yv_next);
     } else if (G::PW == 2) {
@@ -342,9 +372,9 @@ __device__ __forceinline__ void nw_batch_steps(int t0, int lane, int n, int go, 
     passH = up;
     passF = uf;
     yv = yv_next;
-#pragma unroll
-    for (int i = 0; i < G::PW; ++i) pw[i] = pw_next[i];
   }
+#pragma unroll
+  for (int i = 0; i < G::PW; ++i) pw_io[i] = pwb[0][i];
 #pragma unroll
   for (int k = 0; k < K; ++k) tdst[k] = tacc[k];
 }
@@ -544,7 +574,7 @@ __global__ void __launch_bounds__(64) lcs_batch_kernel(const BatchArgs a) {
       const int t = t0 + u;
       int up = dpp_shr1(1, passH);  // lane 0 sits under row 0: L = 0
       const int yv = dpp_shr1(yb, ypass);
-      yb = dpp_shl1(yb, yb);
+      yb = dpp_shl1_any(yb);  // lane 63 is reloaded before it matters
       if (u == 15 && ((t0 + 16) & 63) == 0) yb = ysym(t + 1 + lane);
       ypass = yv;
       int diag = dprev;
@@ -555,7 +585,8 @@ __global__ void __launch_bounds__(64) lcs_batch_kernel(const BatchArgs a) {
         const int dc = (xr[k] == (uint32_t)yv) ? diag + 6 : 0;
         const int ht = max(max(dc, up + 1), left);
         tacc[k] = __builtin_amdgcn_alignbit((uint32_t)ht, tacc[k], 2);
-        const int h = (ht & ~3) | 1;
+        int h;
+        asm("v_and_or_b32 %0, %1, -4, 1" : "=v"(h) : "v"(ht));  // (ht & ~3) | 1 in one op, as in sa_kernels.h
         diag = left;
         H[k] = h;
         up = h;

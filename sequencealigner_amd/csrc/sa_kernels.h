@@ -93,6 +93,8 @@ __device__ __forceinline__ int dpp_shr1(int old, int src) {  // lane l <- src of
 __device__ __forceinline__ int dpp_shl1(int old, int src) {  // lane l <- src of lane l+1, lane 63 <- old
   return __builtin_amdgcn_update_dpp(old, src, 0x130, 0xf, 0xf, false);
 }
+// lane l <- src of lane l-1, lane 0 <- 0 through DPP's bound_ctrl: no register has to hold the zero
+__device__ __forceinline__ int dpp_shr1_zero(int src) { return __builtin_amdgcn_update_dpp(0, src, 0x138, 0xf, 0xf, true); }
 // rotate-left whose lane 63 is a don't-care: no tie to an old value, so no register copy
 __device__ __forceinline__ int dpp_shl1_any(int src) { return __builtin_amdgcn_mov_dpp(src, 0x130, 0xf, 0xf, false); }
 

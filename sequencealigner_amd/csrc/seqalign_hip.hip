@@ -1254,9 +1254,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
         if (glo >= ghi) continue;
         a.desc = (const PairDesc*)ctx->b_desc.p + glo;
         a.n_desc = (int)(ghi - glo);
-        int CB = 8;
-        while ((1 << CB) < group_nmax[K] + 160) ++CB;
-        a.CB = CB;
+        a.CB = kBatchCB;
         if (lcs)
           launch_lcs_batch_k(K, st, a.n_desc, a);
         else if (al && al->kind == KIND_NW)
