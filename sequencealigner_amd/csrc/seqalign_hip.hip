@@ -29,6 +29,10 @@ struct Buf {
   void* p = nullptr;
   size_t cap = 0;
 };
+struct HostBuf {  // page-locked host staging, grow-only
+  void* p = nullptr;
+  size_t cap = 0;
+};
 
 }  // namespace
 
@@ -47,6 +51,7 @@ struct sa_ctx {
   Buf xenc, yenc, prof, sub, colb, bot, state, trace, rowbest, small, ops;
   // batch workspaces
   Buf b_seq, b_desc, b_out;
+  HostBuf h_desc, h_out;  // pair descriptors / per-pair results: copied at PCIe speed, never zero-filled
   const uint8_t* dev_pool = nullptr;  // sa_batch_set_device_pool: the batch entry points read the sequences here
   int64_t dev_pool_bytes = 0;
   Buf lbuf, dpbuf, pbuf;
@@ -82,6 +87,22 @@ int fail(sa_ctx* ctx, int code, const char* fmt, ...) {
       return fail(ctx, e_ == hipErrorOutOfMemory ? SA_ERR_NOMEM : SA_ERR_HIP, "%s failed: %s (%s:%d)", #call, \
                   hipGetErrorString(e_), __FILE__, __LINE__);                                       \
   } while (0)
+
+int ensure_host(sa_ctx* ctx, HostBuf& b, size_t bytes) {
+  if (bytes <= b.cap) return SA_OK;
+  if (b.p) (void)hipHostFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+  const size_t want = (bytes + (bytes >> 2) + 4095) & ~size_t(4095);
+  hipError_t e = hipHostMalloc(&b.p, want, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    b.p = nullptr;
+    return fail(ctx, SA_ERR_NOMEM, "hipHostMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+  }
+  b.cap = want;
+  return SA_OK;
+}
 
 int ensure(sa_ctx* ctx, Buf& b, size_t bytes) {
   if (bytes <= b.cap) return SA_OK;
@@ -1137,9 +1158,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
   } guard{al};
 
   // group by rows-per-lane K = ceil(m/64); counting sort keeps the caller's order inside a group
-  std::vector<PairDesc> desc;
-  desc.reserve((size_t)n_pairs);
-  std::vector<int64_t> slow, empty_side;
+  std::vector<int64_t> slow, empty_side, zeros;
   std::vector<int> group_count(17, 0), group_nmax(17, 0);
   int64_t pool_end = 0;
   for (int64_t k = 0; k < n_pairs; ++k) {
@@ -1148,6 +1167,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     if (len_x[k] == 0 || len_y[k] == 0) {
       score[k] = 0;
       end_i[k] = end_j[k] = 0;
+      zeros.push_back(k);
       if (al && al->kind != KIND_SW) empty_side.push_back(k);  // a border walk (main.cpp: row 0 / column 0)
     } else if (len_x[k] > kBatchMaxM || len_y[k] > kBatchMaxN - 200) {
       if (al && al->diag_only)
@@ -1160,6 +1180,8 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
       group_nmax[K] = std::max(group_nmax[K], len_y[k]);
     }
   }
+  PairDesc* desc = nullptr;  // page-locked, sorted by K (big pairs first)
+  size_t n_desc = 0;
   std::vector<int> group_start(18, 0);
   for (int K = 16; K >= 1; --K) group_start[K - 1 >= 0 ? K - 1 : 0] = 0;  // (filled below)
   {
@@ -1168,7 +1190,9 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
       group_start[K] = acc;
       acc += group_count[K];
     }
-    desc.resize((size_t)acc);
+    n_desc = (size_t)acc;
+    if (int rcd = ensure_host(ctx, ctx->h_desc, std::max<size_t>(n_desc, 1) * sizeof(PairDesc))) return rcd;
+    desc = (PairDesc*)ctx->h_desc.p;
     std::vector<int> cur(group_start.begin(), group_start.end());
     for (int64_t k = 0; k < n_pairs; ++k) {
       if (len_x[k] == 0 || len_y[k] == 0 || len_x[k] > kBatchMaxM || len_y[k] > kBatchMaxN - 200) continue;
@@ -1181,9 +1205,9 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
   int h_err = 0;
   if (resident && pool_end > ctx->dev_pool_bytes)
     return fail(ctx, SA_ERR_ARG, "a pair ends at byte %lld of a %lld-byte device pool", (long long)pool_end, (long long)ctx->dev_pool_bytes);
-  if (!desc.empty()) {
+  if (n_desc) {
     if (!resident && (rc = ensure(ctx, ctx->b_seq, (size_t)pool_end + 64))) return rc;
-    if ((rc = ensure(ctx, ctx->b_desc, desc.size() * sizeof(PairDesc)))) return rc;
+    if ((rc = ensure(ctx, ctx->b_desc, n_desc * sizeof(PairDesc)))) return rc;
     if ((rc = ensure(ctx, ctx->b_out, (size_t)n_pairs * 24 + 1024 + 2048))) return rc;
     // aligning variant: cut the (K-sorted) pair list into chunks whose codes fit the trace budget
     // (code offsets are relative to the chunk's buffer); the op slots of ALL pairs live in one
@@ -1196,7 +1220,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     if (al) {
       const long long budget = (long long)ctx->batch_trace_budget / 4;
       Chunk c{0, 0, 0, 0};
-      for (size_t q = 0; q < desc.size(); ++q) {
+      for (size_t q = 0; q < n_desc; ++q) {
         const long long td = batch_trace_dwords(desc[q].m, desc[q].n);
         if (c.hi > c.lo && c.trace_dwords + td > budget) {
           chunks.push_back(c);
@@ -1215,7 +1239,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
       if ((rc = ensure(ctx, ctx->ops, (size_t)pool_total + 64))) return rc;
     }
     if (!resident) HIPCK(ctx, hipMemcpyAsync(ctx->b_seq.p, seqs, (size_t)pool_end, hipMemcpyHostToDevice, st));
-    HIPCK(ctx, hipMemcpyAsync(ctx->b_desc.p, desc.data(), desc.size() * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+    HIPCK(ctx, hipMemcpyAsync(ctx->b_desc.p, desc, n_desc * sizeof(PairDesc), hipMemcpyHostToDevice, st));
     int* d_score = (int*)ctx->b_out.p;
     int* d_ei = d_score + n_pairs;
     int* d_ej = d_ei + n_pairs;
@@ -1244,7 +1268,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     a.n_ops = d_nops;
     a.start_i = d_si;
     a.start_j = d_sj;
-    if (!al) chunks.push_back({0, desc.size(), 0, 0});
+    if (!al) chunks.push_back({0, n_desc, 0, 0});
     float ms_total = 0;
     for (const auto& ch : chunks) {
       HIPCK(ctx, hipEventRecord(ctx->ev[0], st));
@@ -1283,12 +1307,24 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     }
     if (al && pool_total > 0) HIPCK(ctx, hipMemcpyAsync(*al->pool, ctx->ops.p, (size_t)pool_total, hipMemcpyDeviceToHost, st));
     // results come back for every index; slots of pairs handled elsewhere are overwritten below
-    std::vector<int> h_out((size_t)n_pairs * 6);
-    HIPCK(ctx, hipMemcpyAsync(h_out.data(), d_score, (size_t)n_pairs * (al ? 24 : 12), hipMemcpyDeviceToHost, st));
-    HIPCK(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
-    HIPCK(ctx, hipStreamSynchronize(st));
     if (kernel_ms) *kernel_ms = ms_total;
-    for (const PairDesc& d : desc) {
+    if (!al) {  // the kernels wrote in the caller's order: straight into the caller's arrays
+      HIPCK(ctx, hipMemcpyAsync(score, d_score, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+      HIPCK(ctx, hipMemcpyAsync(end_i, d_ei, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+      HIPCK(ctx, hipMemcpyAsync(end_j, d_ej, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+      HIPCK(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
+      HIPCK(ctx, hipStreamSynchronize(st));
+      for (int64_t k : zeros) score[k] = end_i[k] = end_j[k] = 0;  // their device slots were never written
+      n_desc = 0;
+    } else {
+      if ((rc = ensure_host(ctx, ctx->h_out, (size_t)n_pairs * 24))) return rc;
+      HIPCK(ctx, hipMemcpyAsync(ctx->h_out.p, d_score, (size_t)n_pairs * 24, hipMemcpyDeviceToHost, st));
+      HIPCK(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
+      HIPCK(ctx, hipStreamSynchronize(st));
+    }
+    const int* h_out = (const int*)ctx->h_out.p;
+    for (size_t q = 0; q < n_desc; ++q) {
+      const PairDesc& d = desc[q];
       score[d.idx] = h_out[(size_t)d.idx];
       end_i[d.idx] = h_out[(size_t)n_pairs + d.idx];
       end_j[d.idx] = h_out[(size_t)2 * n_pairs + d.idx];
@@ -1455,6 +1491,11 @@ int sa_release_workspace(sa_ctx* c) {
   for (Buf* b : {&c->xenc, &c->yenc, &c->prof, &c->sub, &c->colb, &c->bot, &c->state, &c->trace, &c->rowbest, &c->small,
                  &c->ops, &c->b_seq, &c->b_desc, &c->b_out, &c->lbuf, &c->dpbuf, &c->pbuf})
     release(*b);
+  for (HostBuf* h : {&c->h_desc, &c->h_out}) {
+    if (h->p) (void)hipHostFree(h->p);
+    h->p = nullptr;
+    h->cap = 0;
+  }
   return SA_OK;
 }
 
