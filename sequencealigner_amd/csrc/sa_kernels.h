@@ -155,7 +155,7 @@ template <int KIND, int K, bool BND, int FLAGS>
 __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF, int& yb, int& obH, int& obF,
                                           uint32_t (&tacc)[K], const int u, const char* ldsLane,
                                           const uint32_t (&xr)[K], const FillArgs& a, const int c, int* dprow,
-                                          uint32_t (&sbk)[K]) {
+                                          uint32_t (&sbk)[K], uint32_t (&skp)[K]) {
   constexpr bool FRAC = (FLAGS & FLAG_FRAC) != 0;
   constexpr bool DUMP = (FLAGS & FLAG_DUMP) != 0;
   const int go = a.go, ge = a.ge, n = a.n;
@@ -244,7 +244,16 @@ __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF,
       // h = 4 * score < 2^29 (check_scoring), so the key stays below 2^31.
       uint32_t key = ((uint32_t)h << 2) + (uint32_t)(15 - u);
       if (BND) key = act ? key : 0u;
-      sbk[k] = max(sbk[k], key);
+      // Two steps share one v_max3_u32: the even step parks its key, the odd one folds both.  Here and now
+      // (the empty asm): left alone the compiler sinks all 16 x K key computations to the end of the
+      // sub-block and keeps every cell's value alive until then (spills once the four sub-blocks are in line).
+      if ((u & 1) == 0) {
+        skp[k] = key;
+        asm volatile("" : "+v"(skp[k]));
+      } else {
+        sbk[k] = max(max(sbk[k], skp[k]), key);
+        asm volatile("" : "+v"(sbk[k]));
+      }
     }
     if (DUMP) {
       if (act && dprow[k] >= 0) a.dp[(size_t)dprow[k] + c + 1] = h >> 2;
@@ -315,24 +324,24 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
                                           const int lane, const char* ldsLane, const uint32_t (&xr)[K], int* dprow,
                                           int ibH, int ibF, int yb, Hook&& hook) {
   constexpr bool PERSIST = (FLAGS & FLAG_PERSIST) != 0;
-  // The persistent NW / LCS kernels expand the four sub-blocks in line: values prefetched in one
+  // The persistent kernels expand the four sub-blocks in line: values prefetched in one
   // sub-block and used in a later one then stay in their registers (a loop makes them
-  // loop-carried copies, and the compiler waits for a load before it copies its result).  The SW
-  // body is too large for that (it spills), so it keeps the loop.
-  constexpr int kUnroll = (PERSIST && KIND != KIND_SW) ? kSubUnroll : 1;
+  // loop-carried copies, and the compiler waits for a load before it copies its result).  For SW
+  // this fits the register file only because lane_step pins its first-maximum keys in place.
+  constexpr int kUnroll = PERSIST ? kSubUnroll : 1;
   int* wrH = a.botH + (size_t)wr_slot(a, s) * a.NP;
   int* wrF = a.botF + (size_t)wr_slot(a, s) * a.NP;
   int obH = 0, obF = 0;
   uint32_t* tdst = a.trace + (((size_t)(s - a.trace_s0) * a.W + (Tb >> 4)) * 64 + lane) * K;
 #pragma unroll kUnroll
   for (int sub = 0; sub < 4; ++sub) {
-    uint32_t tacc[K], sbk[K];
+    uint32_t tacc[K], sbk[K], skp[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) tacc[k] = 0, sbk[k] = 0;
+    for (int k = 0; k < K; ++k) tacc[k] = 0, sbk[k] = 0, skp[k] = 0;
     const int cbase = Tb + 16 * sub - lane;
 #pragma unroll
     for (int u = 0; u < 16; ++u)
-      lane_step<KIND, K, BND, FLAGS>(st, ibH, ibF, yb, obH, obF, tacc, u, ldsLane, xr, a, cbase + u, dprow, sbk);
+      lane_step<KIND, K, BND, FLAGS>(st, ibH, ibF, yb, obH, obF, tacc, u, ldsLane, xr, a, cbase + u, dprow, sbk, skp);
     if (KIND == KIND_SW) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
