@@ -98,7 +98,9 @@ __device__ __forceinline__ int dpp_shr1_zero(int src) { return __builtin_amdgcn_
 // rotate-left whose lane 63 is a don't-care: no tie to an old value, so no register copy
 __device__ __forceinline__ int dpp_shl1_any(int src) { return __builtin_amdgcn_mov_dpp(src, 0x130, 0xf, 0xf, false); }
 
-enum { FLAG_FRAC = 1, FLAG_DUMP = 2, FLAG_PERSIST = 4, FLAG_NOTRACE = 8 };
+// FLAG_LPROF (persistent LCS, at most 31 distinct bytes in the pair): the match term comes from an LDS profile
+// like the NW one (byte +6 on a match, -62 otherwise: one SDWA add) instead of a compare and a select per cell.
+enum { FLAG_FRAC = 1, FLAG_DUMP = 2, FLAG_PERSIST = 4, FLAG_NOTRACE = 8, FLAG_LPROF = 16 };
 #ifndef SA_SUB_UNROLL
 #define SA_SUB_UNROLL 4
 #endif
@@ -175,8 +177,9 @@ __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF,
   ibH = nibH;
   yb = nyb;
 
+  constexpr bool LPROF = (FLAGS & FLAG_LPROF) != 0;
   uint32_t pw[G::PW];
-  if (KIND != KIND_LCS) {
+  if (KIND != KIND_LCS || LPROF) {
     if (G::PW == 1) {
       pw[0] = *reinterpret_cast<const uint32_t*>(ldsLane + yv);
     } else {
@@ -200,8 +203,8 @@ __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF,
       // becomes the UP candidate with + 1 (tag 2) and the diagonal one, on a match, 4 * (L_diag + 1) + 3.
       // A match always wins (L_diag + 1 >= L_up, L_left), a tie between up and left goes to up
       // (main.cpp:1581), so one max3 yields value and direction: 7 ops per cell, no compare masks.
-      const bool eq = (xr[k] == (uint32_t)yv);
-      const int dc = eq ? diag + 6 : 0;
+      // a mismatch (diag - 62) can never reach `left` (L[i][j-1] >= L[i-1][j-1])
+      const int dc = LPROF ? diag + (int)(int8_t)(pw[k / 4] >> (8 * (k & 3))) : ((xr[k] == (uint32_t)yv) ? diag + 6 : 0);
       const int ht = max(max(dc, up + 1), left);
       tacc[k] = __builtin_amdgcn_alignbit((uint32_t)ht, tacc[k], 2);
       // one v_and_or_b32; written as C the compiler splits it into an AND and two ORs per cell
@@ -310,7 +313,7 @@ __device__ __forceinline__ void load_block_inputs(const FillArgs& a, const int s
     if (KIND != KIND_LCS) ibF = rdF[Tb + 64 + lane];
   }
   yb = a.yenc[Tb + lane];
-  if (KIND != KIND_LCS && !RAW_Y) yb *= G::ROWB;
+  if ((KIND != KIND_LCS || (FLAGS & FLAG_LPROF)) && !RAW_Y) yb *= G::ROWB;
 }
 
 struct NoHook {
@@ -555,7 +558,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
     const int rowg = s * 64 + lane;
     const int r0 = rowg * K;
     uint32_t xr[K];
-    if (KIND == KIND_LCS) {
+    if (KIND == KIND_LCS && !(FLAGS & FLAG_LPROF)) {
 #pragma unroll
       for (int k = 0; k < K; ++k) xr[k] = a.xpad[(size_t)r0 + k];
     } else {
@@ -613,7 +616,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
       if (have_next) {
         ibH = nH;
         ibF = nF;
-        yb = (KIND != KIND_LCS) ? ny * G::ROWB : ny;
+        yb = (KIND != KIND_LCS || (FLAGS & FLAG_LPROF)) ? ny * G::ROWB : ny;
       } else {
         if (has_up) {
           const int need = min(b + 2, NB);

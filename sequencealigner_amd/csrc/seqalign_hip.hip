@@ -60,7 +60,7 @@ struct sa_ctx {
     int valid = 0, kind = 0, m = 0, n = 0, K = 0, W = 0, first_stripe = 1;
     // checkpointed fill: the codes did not fit, only every strip's bottom row was kept; the
     // traceback recomputes `band` strips at a time from these arguments
-    int ckpt = 0, band = 0, S = 0;
+    int ckpt = 0, band = 0, S = 0, lprof = 0;
     sa::FillArgs args;
     size_t lds = 0;
   } last;
@@ -177,9 +177,9 @@ double pipeline_steps(double S, double waves, double n) {
 // Rows per lane for the persistent pipeline on one GPU: the schedule above priced with the measured
 // step cost (choose_stripe_K below).  E.g. 786 432 rows: K=8 gives 1536 strips = 2 rounds with half
 // the waves idle in the second, K=4 gives 3 full rounds of cheaper steps and wins by 10 %.
-int choose_persist_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n) {
+int choose_persist_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n, bool lprof = false) {
   if (ctx->force_K) return ctx->force_K;
-  const double cell = kind == KIND_LCS ? 7.0 : (kind == KIND_SW ? 13.0 : 10.0);
+  const double cell = kind == KIND_LCS ? (lprof ? 5.0 : 7.0) : (kind == KIND_SW ? 12.0 : 10.0);
   const double waves = 4.0 * ctx->n_cu * std::max(1, ctx->wps);
   double best = 1e300;
   int bestK = 1;
@@ -203,8 +203,8 @@ int choose_persist_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n) {
 // slowest per step, so the more GPUs share the columns, the smaller K gets.  Step costs measured
 // on MI355X (tools/perf_stripe_model.py): (10 K + 18) issue slots of 4 cycles for NW.
 // R > 0: K must divide the border chunk into whole strips.
-int choose_stripe_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n, int64_t n_total, int64_t R) {
-  const double cell = kind == KIND_LCS ? 7.0 : (kind == KIND_SW ? 13.0 : 10.0);
+int choose_stripe_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n, int64_t n_total, int64_t R, bool lprof = false) {
+  const double cell = kind == KIND_LCS ? (lprof ? 5.0 : 7.0) : (kind == KIND_SW ? 12.0 : 10.0);
   const double step0 = 18.0;
   const double waves = 4.0 * ctx->n_cu * std::max(1, ctx->wps);
   double best = 1e300;
@@ -246,8 +246,24 @@ void launch_fill(int K, int fl, dim3 grid, size_t lds, hipStream_t st, const Fil
 
 // notrace: the FLAG_NOTRACE instances (score-only calls, the checkpoint pass): no codes are packed or stored
 template <int KIND>
-void launch_persistent(int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a, bool notrace = false) {
+void launch_persistent(int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a, bool notrace = false, bool lprof = false) {
   const dim3 blk(64 * kWavesPerBlock);
+  if constexpr (KIND == KIND_LCS) {
+    if (lprof) {  // profile-driven LCS (small alphabets)
+      constexpr int F = FLAG_LPROF, FN = FLAG_LPROF | FLAG_NOTRACE;
+      switch (notrace ? -K : K) {
+        case 1: hipLaunchKernelGGL((fill_persistent<KIND, 1, F>), grid, blk, lds, st, a); break;
+        case 2: hipLaunchKernelGGL((fill_persistent<KIND, 2, F>), grid, blk, lds, st, a); break;
+        case 4: hipLaunchKernelGGL((fill_persistent<KIND, 4, F>), grid, blk, lds, st, a); break;
+        case 8: hipLaunchKernelGGL((fill_persistent<KIND, 8, F>), grid, blk, lds, st, a); break;
+        case -1: hipLaunchKernelGGL((fill_persistent<KIND, 1, FN>), grid, blk, lds, st, a); break;
+        case -2: hipLaunchKernelGGL((fill_persistent<KIND, 2, FN>), grid, blk, lds, st, a); break;
+        case -4: hipLaunchKernelGGL((fill_persistent<KIND, 4, FN>), grid, blk, lds, st, a); break;
+        default: hipLaunchKernelGGL((fill_persistent<KIND, 8, FN>), grid, blk, lds, st, a); break;
+      }
+      return;
+    }
+  }
   if (notrace) {
     switch (K) {
       case 1: hipLaunchKernelGGL((fill_persistent<KIND, 1, FLAG_NOTRACE>), grid, blk, lds, st, a); break;
@@ -373,15 +389,31 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   const bool striped = sd && !(sd->is_first && sd->is_last);
   const bool persist = ctx->persist && fl == 0 &&
                        (!striped || ((!ev_in || sd->stream_in) && (!ev_out || (sd->stream_out && R % 64 == 0))));
+  // LCS over a small alphabet (DNA, proteins: at most 31 distinct bytes in the pair) takes its match term from an
+  // LDS profile (FLAG_LPROF); any other input keeps the byte compare
+  uint8_t lmap[256];
+  bool lprof = false;
+  if (kind == KIND_LCS && persist) {
+    bool seen[256] = {false};
+    for (int i = 0; i < m; ++i) seen[x[i]] = true;
+    for (int j = 0; j < n; ++j) seen[y[j]] = true;
+    int A = 0;
+    for (int b = 0; b < 256; ++b)
+      if (seen[b]) lmap[b] = (uint8_t)std::min(A++, 255);
+    if (A <= 31) {
+      lprof = true;
+      alpha = A + 1;  // + the padding symbol
+    }
+  }
   if (fl & FLAG_DUMP) {
     tun.K = 1, tun.C = 64;
   } else if (fl & FLAG_FRAC) {
     tun.K = 2;
   } else if (persist && striped) {
-    tun.K = choose_stripe_K(ctx, kind, m, n, sd->n_total, ev_out ? R : 0);
+    tun.K = choose_stripe_K(ctx, kind, m, n, sd->n_total, ev_out ? R : 0, lprof);
     tun.C = 64;
   } else if (persist) {
-    tun.K = choose_persist_K(ctx, kind, m, n);
+    tun.K = choose_persist_K(ctx, kind, m, n, lprof);
     tun.C = 64;
   }
   const int K = tun.K, C = tun.C;
@@ -442,7 +474,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   const size_t pbuf_ints = (size_t)S + 64 + (size_t)n_chunks;
   if (persist && (rc = ensure(ctx, ctx->pbuf, pbuf_ints * 4))) return rc;
   if ((rc = ensure(ctx, ctx->ops, (size_t)m + n + 64))) return rc;
-  if (kind != KIND_LCS) {
+  if (kind != KIND_LCS || lprof) {
     if ((rc = ensure(ctx, ctx->prof, (size_t)S * alpha * 64 * PW * 4))) return rc;
     if ((rc = ensure(ctx, ctx->sub, 32 * 32))) return rc;
   }
@@ -453,7 +485,11 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
 
   // host-side encoding (O(m+n))
   std::vector<uint8_t> xe(rows_pad + 64, 0), ye((size_t)Tend + 256, 0);
-  if (kind == KIND_LCS) {
+  if (lprof) {
+    for (int i = 0; i < m; ++i) xe[i] = lmap[x[i]];
+    std::fill(ye.begin(), ye.end(), (uint8_t)(alpha - 1));  // padding symbol: matches nothing
+    for (int j = 0; j < n; ++j) ye[j] = lmap[y[j]];
+  } else if (kind == KIND_LCS) {
     memcpy(xe.data(), x, (size_t)m);
     memcpy(ye.data(), y, (size_t)n);
   } else {
@@ -513,7 +549,15 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   int* d_score = (int*)ctx->small.p;                                           // [0]   NW/LCS score / SW best
   unsigned long long* d_pos = (unsigned long long*)((char*)ctx->small.p + 8);  // [8]   SW end cell
   if (kind == KIND_SW) HIPCK(ctx, hipMemsetAsync(d_pos, 0xff, 8, st));
-  if (kind != KIND_LCS) {
+  int8_t lsub[32 * 32];
+  if (lprof) {
+    // build_profile stores 4 v + 2: v = 1 gives the match increment 6 (4 (L + 1) + 3 from 4 L + 1), v = -16 gives -62
+    for (int i = 0; i < alpha; ++i)
+      for (int j = 0; j < alpha; ++j) lsub[i * alpha + j] = (i == j && i < alpha - 1) ? 1 : -16;
+    HIPCK(ctx, hipMemcpyAsync(ctx->sub.p, lsub, (size_t)alpha * alpha, hipMemcpyHostToDevice, st));
+    HIPCK(ctx, hipStreamSynchronize(st));  // lsub is on the stack
+    launch_profile(K, st, (const uint8_t*)ctx->xenc.p, m, (const int8_t*)ctx->sub.p, alpha, S, (uint32_t*)ctx->prof.p);
+  } else if (kind != KIND_LCS) {
     HIPCK(ctx, hipMemcpyAsync(ctx->sub.p, sc->sub, (size_t)alpha * alpha, hipMemcpyHostToDevice, st));
     launch_profile(K, st, (const uint8_t*)ctx->xenc.p, m, (const int8_t*)ctx->sub.p, alpha, S, (uint32_t*)ctx->prof.p);
   }
@@ -548,7 +592,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   a.rowbestc = a.rowbest ? a.rowbest + m : nullptr;
   a.score_out = d_score;
 
-  const size_t lds = (kind == KIND_LCS) ? 0 : (size_t)alpha * 64 * PW * 4 * kWavesPerBlock;
+  const size_t lds = (kind == KIND_LCS && !lprof) ? 0 : (size_t)alpha * 64 * PW * 4 * kWavesPerBlock;
   auto f_lo = [&](int s) { return (long long)s + (64LL * s) / C; };
   auto f_hi = [&](int s) { return (long long)s + (64LL * s + n + 62) / C; };
   const long long dmax = f_hi(S - 1);
@@ -580,7 +624,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
     else if (kind == KIND_SW)
       launch_persistent<KIND_SW>(K, grid, lds, st, a, ckpt || no_tb);
     else
-      launch_persistent<KIND_LCS>(K, grid, lds, st, a, ckpt || no_tb);
+      launch_persistent<KIND_LCS>(K, grid, lds, st, a, ckpt || no_tb, lprof);
     launches = 1;
     // border hand-offs, all enqueued now and resolved on the device while the fill runs
     for (int64_t k = 0; k < n_chunks && (a.rows_in || a.chunk_done); ++k) {
@@ -647,6 +691,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   ctx->last.S = S;
   ctx->last.args = a;
   ctx->last.lds = lds;
+  ctx->last.lprof = lprof;
   return SA_OK;
 }
 
@@ -694,7 +739,7 @@ int traceback_ckpt(sa_ctx* ctx, int start_i, int start_j, sa_result* out) {
     else if (kind == KIND_SW)
       launch_persistent<KIND_SW>(K, grid, ctx->last.lds, st, a);
     else
-      launch_persistent<KIND_LCS>(K, grid, ctx->last.lds, st, a);
+      launch_persistent<KIND_LCS>(K, grid, ctx->last.lds, st, a, false, ctx->last.lprof != 0);
     ++out->n_launches;
     TraceArgs t{};
     t.kind = kind;

@@ -114,3 +114,17 @@ def test_checkpointed_traceback_equals_oracle(engine, oracle):
     finally:
         engine.set_option("checkpoint_band", 0)
         engine.set_tuning(0, 0)
+
+
+def test_lcs_large_alphabet_keeps_the_compare_kernel(engine, oracle):
+    """LCS takes its match term from an LDS profile when the pair holds at most 31 distinct bytes; beyond
+    that (and for every byte value, 0 and 255 included) the byte-compare kernel runs: same results."""
+    rng = np.random.default_rng(77)
+    for nsym in (2, 31, 32, 200, 256):
+        syms = rng.permutation(256)[:nsym].astype(np.uint8)
+        if nsym == 256:
+            syms = np.arange(256, dtype=np.uint8)
+        x = syms[rng.integers(0, nsym, 1500)]
+        y = np.concatenate([x[200:900], syms[rng.integers(0, nsym, 400)], x[1000:1400]])
+        g, o = engine.lcs(x, y), oracle.lcs(x, y)
+        assert g.score == o.score and np.array_equal(g.ops, o.ops), nsym
