@@ -42,6 +42,7 @@ struct BatchArgs {
   int alpha;
   int go, ge;
   int CB;                 // column bits of the tracking key
+  int ycap;               // LDS bytes reserved for the encoded target (sized for the longest target of the launch)
   int* score;
   int* end_i;
   int* end_j;
@@ -77,7 +78,7 @@ __device__ __forceinline__ int max3_i32(int x, int y, int z) {
 
 template <int K>
 struct BatchGeo {
-  static constexpr int PW = (K <= 4) ? 1 : (K <= 8 ? 2 : 4);  // profile dwords per (symbol, lane)
+  static constexpr int PW = (K + 3) / 4;  // profile dwords per (symbol, lane): 1..4 (lane stride 12 B is conflict-free too)
   static constexpr int ROWB = 64 * PW * 4;
 };
 
@@ -89,13 +90,13 @@ template <int K, bool TRACE>
 __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
   using G = BatchGeo<K>;
   extern __shared__ uint32_t lds[];
-  // LDS layout: prof[(alpha+1)][64][PW] dwords | yenc[kBatchMaxN + 192] bytes | map[256] | sub[alpha*alpha]
+  // LDS layout: prof[(alpha+1)][64][PW] dwords | yenc[a.ycap] bytes | map[256] | sub[alpha*alpha]
   const int lane = threadIdx.x;
   const PairDesc pd = a.desc[blockIdx.x];
   const int m = pd.m, n = pd.n, alpha = a.alpha;
   uint32_t* prof = lds;
   uint8_t* yenc = reinterpret_cast<uint8_t*>(lds + (alpha + 1) * 64 * G::PW);
-  uint8_t* map = yenc + kBatchMaxN + 256;
+  uint8_t* map = yenc + a.ycap;
   int8_t* subt = reinterpret_cast<int8_t*>(map + 256);
 
   for (int i = lane; i < 256; i += 64) map[i] = a.idx256[i];
@@ -173,6 +174,11 @@ __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
       const uint2 t = *reinterpret_cast<const uint2*>(ldsLane + yv);
       pw[0] = t.x;
       pw[G::PW - 1] = t.y;
+    } else if (G::PW == 3) {
+      const uint32_t* t = reinterpret_cast<const uint32_t*>(ldsLane + yv);
+      pw[0] = t[0];
+      pw[1 % G::PW] = t[1];
+      pw[2 % G::PW] = t[2];
     } else {
       const uint4 t = *reinterpret_cast<const uint4*>(ldsLane + yv);
       pw[0] = t.x;
@@ -332,6 +338,11 @@ __device__ __forceinline__ void nw_batch_steps(int t0, int lane, int n, int go, 
       const uint2 q = *reinterpret_cast<const uint2*>(ldsLane + yv_next);
       pw_next[0] = q.x;
       pw_next[G::PW - 1] = q.y;
+    } else if (G::PW == 3) {
+      const uint32_t* q = reinterpret_cast<const uint32_t*>(ldsLane + yv_next);
+      pw_next[0] = q[0];
+      pw_next[1 % G::PW] = q[1];
+      pw_next[2 % G::PW] = q[2];
     } else {
       const uint4 q = *reinterpret_cast<const uint4*>(ldsLane + yv_next);
       pw_next[0] = q.x;
@@ -388,7 +399,7 @@ __global__ void __launch_bounds__(64) nw_batch_kernel(const BatchArgs a) {
   const int m = pd.m, n = pd.n, alpha = a.alpha;
   uint32_t* prof = lds;
   uint8_t* yenc = reinterpret_cast<uint8_t*>(lds + (alpha + 1) * 64 * G::PW);
-  uint8_t* map = yenc + kBatchMaxN + 256;
+  uint8_t* map = yenc + a.ycap;
   int8_t* subt = reinterpret_cast<int8_t*>(map + 256);
   for (int i = lane; i < 256; i += 64) map[i] = a.idx256[i];
   for (int i = lane; i < alpha * alpha; i += 64) subt[i] = a.sub[i];
@@ -457,6 +468,11 @@ __global__ void __launch_bounds__(64) nw_batch_kernel(const BatchArgs a) {
     const uint2 q = *reinterpret_cast<const uint2*>(ldsLane + yv);
     pw[0] = q.x;
     pw[G::PW - 1] = q.y;
+  } else if (G::PW == 3) {
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(ldsLane + yv);
+    pw[0] = q[0];
+    pw[1 % G::PW] = q[1];
+    pw[2 % G::PW] = q[2];
   } else {
     const uint4 q = *reinterpret_cast<const uint4*>(ldsLane + yv);
     pw[0] = q.x;
@@ -728,9 +744,12 @@ __global__ void sw_batch_diag_walk(const BatchArgs a) {
   a.start_j[pd.idx] = sc > 0 ? j : 0;
 }
 
+// room for a target of n residues: the kernels touch ((n + 126) / 64) * 64 + 128 encoded bytes
+inline int batch_ycap(int nmax) { return ((nmax + 126) / 64) * 64 + 128 + 64; }
+
 template <int K>
-inline size_t batch_lds_bytes(int alpha) {
-  return (size_t)(alpha + 1) * 64 * BatchGeo<K>::PW * 4 + (kBatchMaxN + 256) + 256 + (size_t)alpha * alpha + 16;
+inline size_t batch_lds_bytes(int alpha, int ycap) {
+  return (size_t)(alpha + 1) * 64 * BatchGeo<K>::PW * 4 + (size_t)ycap + 256 + (size_t)alpha * alpha + 16;
 }
 
 }  // namespace sa

@@ -1003,14 +1003,14 @@ int run_stripe_traceback(sa_ctx* ctx, int64_t start_i, int64_t start_j, sa_resul
 template <int K>
 void launch_batch(hipStream_t st, int count, int alpha, const BatchArgs& a, bool trace) {
   if (trace)
-    hipLaunchKernelGGL((sw_batch_kernel<K, true>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha), st, a);
+    hipLaunchKernelGGL((sw_batch_kernel<K, true>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha, a.ycap), st, a);
   else
-    hipLaunchKernelGGL((sw_batch_kernel<K, false>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha), st, a);
+    hipLaunchKernelGGL((sw_batch_kernel<K, false>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha, a.ycap), st, a);
 }
 
 template <int K>
 void launch_nw_batch(hipStream_t st, int count, int alpha, const BatchArgs& a) {
-  hipLaunchKernelGGL((nw_batch_kernel<K>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha), st, a);
+  hipLaunchKernelGGL((nw_batch_kernel<K>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha, a.ycap), st, a);
 }
 
 void launch_nw_batch_k(int K, hipStream_t st, int count, int alpha, const BatchArgs& a) {
@@ -1036,7 +1036,7 @@ void launch_nw_batch_k(int K, hipStream_t st, int count, int alpha, const BatchA
 
 template <int K>
 void launch_lcs_batch(hipStream_t st, int count, const BatchArgs& a) {
-  hipLaunchKernelGGL((lcs_batch_kernel<K>), dim3(count), dim3(64), (size_t)kBatchMaxN + 512, st, a);
+  hipLaunchKernelGGL((lcs_batch_kernel<K>), dim3(count), dim3(64), (size_t)a.ycap + 64, st, a);
 }
 
 void launch_lcs_batch_k(int K, hipStream_t st, int count, const BatchArgs& a) {
@@ -1324,6 +1324,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
         a.desc = (const PairDesc*)ctx->b_desc.p + glo;
         a.n_desc = (int)(ghi - glo);
         a.CB = kBatchCB;
+        a.ycap = batch_ycap(group_nmax[K]);
         if (lcs)
           launch_lcs_batch_k(K, st, a.n_desc, a);
         else if (al && al->kind == KIND_NW)
