@@ -861,7 +861,7 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
   TraceWindow nw{0, 0, 0, 0};
   bool stopped = false;
   while (i > i_min && j > 0 && !stopped) {
-    if (nops - flushed > kTraceStage - 192) flush();
+    if (nops - flushed > kTraceStage - 256) flush();
     const int sbase = (int)(nops - flushed);
     if (window_ok(i - i_min, j)) {
       // ---- fast path: 64 rows per memory round trip, the next window already in flight ----
@@ -907,6 +907,21 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
           L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);
           if (d >= dcur && d < dcur + L) stage[sbase + emitted + (d - dcur)] = 0;
           dcur += L;
+          // The cell that ended the run is in the window too: take its move now (isolated indels and LCS
+          // mismatches are runs of one), instead of spending a whole iteration of this serial loop on it.
+          if (dcur < 64) {
+            const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)rM, dcur);
+            if (c1 == rawU) {
+              if (d == 0) stage[sbase + emitted + L] = 2;
+              ++L;
+              ++dcur;
+              ++o;
+            } else if (c1 == 1u) {
+              if (d == 0) stage[sbase + emitted + L] = 1;
+              ++L;
+              --o;
+            }
+          }
         } else if (r0 == rawU) {  // up run: row dcur + k is entered at drift o + k
           const int ol = o + (d - dcur);
           const bool in = d >= dcur && ol <= 15;
