@@ -144,8 +144,8 @@ int sa_batch_set_device_pool(sa_ctx* ctx, const uint8_t* d_seqs, int64_t bytes);
  * cell, the 'X' cell where the traceback stopped, the op list end -> start).  The reference has no
  * batch mode -- it aligns one pair per process (processFasta reads one record, main.cpp:290-308) --
  * so this is localalign()'s fill + traceback (main.cpp:1099-1128, 1182-1265) applied to every pair
- * (SURVEY.md 8f-1).  The ops of pair k are ops_pool[ops_off[k] .. ops_off[k] + n_ops[k]); ops_off[k]
- * is the sum over earlier pairs of (len_x + len_y) rounded up to 4.  *ops_pool is library-owned,
+ * (SURVEY.md 8f-1).  The ops of pair k are ops_pool[ops_off[k] .. ops_off[k] + n_ops[k]); the library
+ * assigns ops_off (slots of len_x + len_y rounded up to 4, in its processing order, not the caller's).  *ops_pool is library-owned,
  * page-locked host memory, released with sa_free_pool() (which keeps one buffer for the next call,
  * so a loop of calls pins memory once).  Device memory for the direction codes is bounded by
  * processing the pairs in chunks (sa_set_option "batch_trace_budget_mb", default 32768).

@@ -39,6 +39,8 @@ struct HostBuf {  // page-locked host staging, grow-only
 struct sa_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // batch alignments: a chunk's moves leave the device while the next chunk computes
+  hipEvent_t ev_chunk = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [4]: stripe flags reset
   std::string err;
@@ -1182,8 +1184,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
       al->n_ops[k] = 0;
       if (al->start_i) al->start_i[k] = al->start_j[k] = 0;
       if (al->diag_only) continue;
-      al->ops_off[k] = pool_total;
-      pool_total += ((int64_t)len_x[k] + len_y[k] + 3) & ~3LL;
+      pool_total += ((int64_t)len_x[k] + len_y[k] + 3) & ~3LL;  // the slots are laid out below, in processing order
     }
     if (!al->diag_only) {
       *al->pool = pool_acquire((size_t)std::max<int64_t>(pool_total, 4));
@@ -1193,14 +1194,16 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
   }
   struct PoolGuard {  // the pool goes back to the caller only with SA_OK / SA_ERR_INVALID_CODE
     const BatchAlign* al;
+    sa_ctx* ctx;
     bool keep = false;
     ~PoolGuard() {
+      if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);  // no copy may outlive the pool
       if (al && al->pool && !keep && *al->pool) {
         pool_release(*al->pool);
         *al->pool = nullptr;
       }
     }
-  } guard{al};
+  } guard{al, ctx};
 
   // group by rows-per-lane K = ceil(m/64); counting sort keeps the caller's order inside a group
   std::vector<int64_t> slow, empty_side, zeros;
@@ -1245,6 +1248,20 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
       desc[(size_t)cur[K]++] = PairDesc{off_x[k], off_y[k], len_x[k], len_y[k], (int)k, 0, 0, 0};
     }
   }
+  if (al && !al->diag_only) {
+    // op slots in PROCESSING order (the K-sorted list, then the pairs handled on the host): the moves of a chunk are
+    // one contiguous range of the pool and can be copied out while the next chunk computes
+    int64_t off = 0;
+    for (size_t q = 0; q < n_desc; ++q) {
+      al->ops_off[desc[q].idx] = off;
+      off += ((int64_t)desc[q].m + desc[q].n + 3) & ~3LL;
+    }
+    for (int64_t k = 0; k < n_pairs; ++k) {
+      if (!(len_x[k] == 0 || len_y[k] == 0 || len_x[k] > kBatchMaxM || len_y[k] > kBatchMaxN - 200)) continue;
+      al->ops_off[k] = off;
+      off += ((int64_t)len_x[k] + len_y[k] + 3) & ~3LL;
+    }
+  }
 
   int rc = SA_OK;
   int h_err = 0;
@@ -1255,8 +1272,8 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     if ((rc = ensure(ctx, ctx->b_desc, n_desc * sizeof(PairDesc)))) return rc;
     if ((rc = ensure(ctx, ctx->b_out, (size_t)n_pairs * 24 + 1024 + 2048))) return rc;
     // aligning variant: cut the (K-sorted) pair list into chunks whose codes fit the trace budget
-    // (code offsets are relative to the chunk's buffer); the op slots of ALL pairs live in one
-    // device image of the caller-ordered pool, which comes back in a single copy at the end
+    // (code offsets are relative to the chunk's buffer); the op slots live in a device image of the
+    // pool, and each chunk's range goes back on the copy stream as soon as its walks are done
     struct Chunk {
       size_t lo, hi;
       long long trace_dwords, ops_bytes;
@@ -1314,6 +1331,11 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     a.start_i = d_si;
     a.start_j = d_sj;
     if (!al) chunks.push_back({0, n_desc, 0, 0});
+    const bool pool_out = al && !al->diag_only && pool_total > 0;
+    if (pool_out && !ctx->copy_stream) {
+      HIPCK(ctx, hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+      HIPCK(ctx, hipEventCreateWithFlags(&ctx->ev_chunk, hipEventDisableTiming));
+    }
     float ms_total = 0;
     for (const auto& ch : chunks) {
       HIPCK(ctx, hipEventRecord(ctx->ev[0], st));
@@ -1346,12 +1368,18 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
       }
       HIPCK(ctx, hipGetLastError());
       HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
+      if (pool_out && ch.ops_bytes > 0) {
+        const int64_t lo = al->ops_off[desc[ch.lo].idx];
+        HIPCK(ctx, hipEventRecord(ctx->ev_chunk, st));
+        HIPCK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->ev_chunk, 0));
+        HIPCK(ctx, hipMemcpyAsync(*al->pool + lo, (const uint8_t*)ctx->ops.p + lo, (size_t)ch.ops_bytes, hipMemcpyDeviceToHost,
+                                  ctx->copy_stream));
+      }
       HIPCK(ctx, hipStreamSynchronize(st));
       float ms = 0;
       HIPCK(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
       ms_total += ms;
     }
-    if (al && pool_total > 0) HIPCK(ctx, hipMemcpyAsync(*al->pool, ctx->ops.p, (size_t)pool_total, hipMemcpyDeviceToHost, st));
     // results come back for every index; slots of pairs handled elsewhere are overwritten below
     if (kernel_ms) *kernel_ms = ms_total;
     if (!al) {  // the kernels wrote in the caller's order: straight into the caller's arrays
@@ -1367,6 +1395,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
       HIPCK(ctx, hipMemcpyAsync(ctx->h_out.p, d_score, (size_t)n_pairs * 24, hipMemcpyDeviceToHost, st));
       HIPCK(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
       HIPCK(ctx, hipStreamSynchronize(st));
+      if (pool_out) HIPCK(ctx, hipStreamSynchronize(ctx->copy_stream));
     }
     const int* h_out = (const int*)ctx->h_out.p;
     for (size_t q = 0; q < n_desc; ++q) {
@@ -1489,6 +1518,8 @@ void sa_destroy(sa_ctx* c) {
   for (auto& e : c->ev)
     if (e) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+  if (c->ev_chunk) (void)hipEventDestroy(c->ev_chunk);
   delete c;
 }
 
