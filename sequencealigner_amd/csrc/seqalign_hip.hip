@@ -1390,27 +1390,30 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
       HIPCK(ctx, hipStreamSynchronize(st));
       for (int64_t k : zeros) score[k] = end_i[k] = end_j[k] = 0;  // their device slots were never written
       n_desc = 0;
-    } else {
-      if ((rc = ensure_host(ctx, ctx->h_out, (size_t)n_pairs * 24))) return rc;
-      HIPCK(ctx, hipMemcpyAsync(ctx->h_out.p, d_score, (size_t)n_pairs * 24, hipMemcpyDeviceToHost, st));
+    } else {  // the same for the aligning variants: six arrays in the caller's order
+      HIPCK(ctx, hipMemcpyAsync(score, d_score, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+      HIPCK(ctx, hipMemcpyAsync(end_i, d_ei, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+      HIPCK(ctx, hipMemcpyAsync(end_j, d_ej, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+      HIPCK(ctx, hipMemcpyAsync(al->n_ops, d_nops, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+      if (al->start_i) {
+        HIPCK(ctx, hipMemcpyAsync(al->start_i, d_si, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+        HIPCK(ctx, hipMemcpyAsync(al->start_j, d_sj, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, st));
+      }
       HIPCK(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
       HIPCK(ctx, hipStreamSynchronize(st));
       if (pool_out) HIPCK(ctx, hipStreamSynchronize(ctx->copy_stream));
-    }
-    const int* h_out = (const int*)ctx->h_out.p;
-    for (size_t q = 0; q < n_desc; ++q) {
-      const PairDesc& d = desc[q];
-      score[d.idx] = h_out[(size_t)d.idx];
-      end_i[d.idx] = h_out[(size_t)n_pairs + d.idx];
-      end_j[d.idx] = h_out[(size_t)2 * n_pairs + d.idx];
-      if (al) {
-        const bool bad = score[d.idx] == INT32_MIN;
-        al->n_ops[d.idx] = bad ? 0 : h_out[(size_t)3 * n_pairs + d.idx];
-        if (al->start_i) {
-          al->start_i[d.idx] = bad ? 0 : h_out[(size_t)4 * n_pairs + d.idx];
-          al->start_j[d.idx] = bad ? 0 : h_out[(size_t)5 * n_pairs + d.idx];
-        }
+      auto clear = [&](int64_t k) {
+        al->n_ops[k] = 0;
+        if (al->start_i) al->start_i[k] = al->start_j[k] = 0;
+      };
+      for (int64_t k : zeros) {  // device slots that were never written
+        score[k] = end_i[k] = end_j[k] = 0;
+        clear(k);
       }
+      for (int64_t k : slow) clear(k);
+      if (h_err)  // a pair with an invalid residue: score INT32_MIN, nothing else
+        for (size_t q = 0; q < n_desc; ++q)
+          if (score[desc[q].idx] == INT32_MIN) clear(desc[q].idx);
     }
   }
   std::vector<uint8_t> hx, hy;  // a resident pool: the single-pair path takes host buffers
