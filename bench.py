@@ -8,8 +8,14 @@ window mirrors the reference's own time_ms window, main.cpp:736 -> :820).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--size L] [--kind nw|lcs|sw]
 
-N = 1 runs the whole matrix on one MI355X.  N > 1 (launched by torch.distributed.run, one
-rank per GPU) column-stripes the same pair over the ranks; see DESIGN.md "Multi-GPU".
+N = 1 runs the whole matrix on one MI355X.  N > 1 column-stripes the same pair over N ranks, one
+process per GPU over RCCL (DESIGN.md "Multi-GPU"): `python bench.py --gpus N` starts the N ranks
+itself (torch.distributed.run as a CHILD process, before anything here touches HIP); started by
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` it is one of the ranks.
+The line also carries the config-5 half of BASELINE.json's metric (batched SW pairs/s) as a
+nested "batch" object measured in the same run (pairs sharded over the ranks; --no-batch skips it).
+
+  python bench.py --gpus 2 --launch-check     # CPU: two gloo ranks report, no GPU work
 
 Prints ONE JSON line on rank 0.
 """
@@ -35,8 +41,30 @@ if int(os.environ.get("WORLD_SIZE", "1")) > 1:
 
 import numpy as np
 
+
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child process (never an
+    exec: nothing in this process has touched the GPU yet, and nothing will), pass rank 0's JSON line
+    through (the child inherits stdout) and return the child's exit code.  The reference's analogue is
+    `mpirun -np P aligner` (main.cpp:1720-1723: MPI_Init, rank, size)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env["GPU_MAX_HW_QUEUES"] = "16"  # see below: one hardware queue per stream of the overlapped stripes
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), str(Path(__file__).resolve())] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
 # algorithmic work per cell (SURVEY.md 8d table): int32 VALU lane-ops and HBM bytes
 OPS_PER_CELL = {"nw": 12, "sw": 14, "lcs": 6}
+OPS_CODE = {"nw": 4, "sw": 4, "lcs": 2}  # of which: the direction code (cmp/select/pack), absent from code-free passes
 HBM_BYTES_PER_CELL = 0.25
 VALU_PEAK_TOPS = 39.3  # 256 CU x 64 lanes x 2.4 GHz int32 lane-ops/s (measured: profiles/probe_valu_r01.txt)
 HBM_PEAK_GBS = 8000.0
@@ -105,20 +133,21 @@ def reference_baseline(x, y, kind, sample):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def bench_batch(args, rank, local_rank, world, dist, torch):
+def bench_batch(args, rank, local_rank, world, dist, torch, workload=None, nested=False):
     """Config 5: independent protein pairs (300-1000 aa, BLOSUM62, -5/-1), SW score + end cell
     (--workload batch) or full local alignments (--workload batch-align: + direction codes, per-pair
     traceback, op lists back on the host).  Pairs are sharded contiguously over the ranks; no
-    data-path collective."""
+    data-path collective.  Returns the result line on rank 0 (None elsewhere)."""
     import sequencealigner_amd as sa
     from sequencealigner_amd.synth import protein_pairs
 
+    workload = workload or args.workload
     per_rank = args.pairs // world
     pool, ox, lx, oy, ly = protein_pairs(per_rank, seed=42 + rank)
     cells = int((lx.astype(np.int64) * ly.astype(np.int64)).sum())
     eng = sa.Engine(local_rank)
-    align = args.workload in ("batch-align", "batch-global")
-    glob = args.workload == "batch-global"
+    align = workload in ("batch-align", "batch-global")
+    glob = workload == "batch-global"
     # The timed region starts with the sequence pool resident in HBM (sa_batch_set_device_pool); the rate with
     # the pool handed over as a host buffer (H2D inside the call) is measured afterwards and reported beside it.
     dev_pool = torch.from_numpy(pool).to(f"cuda:{local_rank}")
@@ -161,7 +190,11 @@ def bench_batch(args, rank, local_rank, world, dist, torch):
         dt, cells_all, kms, dt_host = float(mx[0]), float(tot[1]), float(mx[2]), float(mx[3])
     else:
         cells_all = float(cells)
+    line = None
     if rank == 0:
+        ops = (12 if glob else 14) if align else 10
+        kname = ("nw_batch_kernel<K>" if glob else "sw_batch_kernel<K,TRACE>") if align else "sw_batch_kernel<K>"
+        achieved = cells_all * args.steps * ops / (kms / 1e3) / 1e12 / world
         line = {
             "metric": ("batched NW pairs/s (full global alignments)" if glob else "batched SW pairs/s (full local alignments)") if align else "batched SW pairs/s (score + end cell)", "value": round(per_rank * world * args.steps / dt, 1),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -169,15 +202,17 @@ def bench_batch(args, rank, local_rank, world, dist, torch):
             "vs_baseline": None, "dtype": "int32", "data": "synthetic",
             "config": {"workload": f"{per_rank * world} protein pairs, lengths U[300,1000], uniform residues, BLOSUM62 -5/-1, "
                                    f"sequence pool resident in HBM, descriptors in / results out inside the timed region" + (", op lists back on the host" if align else ""), "parallelism": f"pair sharding x{world}"},
+            "value_note": "`value`: sequence pool resident in HBM when the timed region starts; this is the rate set against cpu_baseline",
             "value_host_pool": round(per_rank * world * args.steps / dt_host, 1),
-            "value_host_pool_note": "same calls with the pool as a pageable host buffer (H2D of the sequences inside every call)",
+            "value_host_pool_note": "same calls with the pool as a pageable host buffer (H2D of the sequences inside every call, PCIe-inclusive)",
             "gcups_end_to_end": round(cells_all * args.steps / dt / 1e9, 1),
             "gcups_kernel_only": round(cells_all * args.steps / (kms / 1e3) / 1e9, 1),
-            "roofline": {"bound": "valu", "achieved": round(cells_all * args.steps * ((12 if glob else 14) if align else 10) / (kms / 1e3) / 1e12 / world, 3),
+            "roofline": {"bound": "valu", "achieved": round(achieved, 3),
                          "peak": VALU_PEAK_TOPS, "unit": "T int32 lane-ops/s",
-                         "frac": round(cells_all * args.steps * ((12 if glob else 14) if align else 10) / (kms / 1e3) / 1e12 / world / VALU_PEAK_TOPS, 4),
-                         "traffic": None, "kernel": ("nw_batch_kernel<K>" if glob else "sw_batch_kernel<K,TRACE>") if align else "sw_batch_kernel",
-                         "ops_per_cell": (12 if glob else 14) if align else 10},
+                         "frac": round(achieved / VALU_PEAK_TOPS, 4),
+                         "traffic": batch_pmc_traffic(workload, per_rank), "traffic_note": "HBM bytes per step (all launches of one call) from the PMC passes in "
+                         "profiles/r02_batch_pmc.json (WRITE_SIZE + 2 x FETCH_SIZE); algorithmic: the sequences once (m + n bytes per pair) + 44 B of descriptor / result per pair",
+                         "kernel": kname, "ops_per_cell": ops},
         }
         if not args.no_cpu and world == 1:
             from oracle import Oracle
@@ -195,8 +230,7 @@ def bench_batch(args, rank, local_rank, world, dist, torch):
                 line["cpu_baseline"] = {"value": round(na / dta, 1), "unit": "pairs/s", "cores": 1, "kind": "port",
                                         "sample": f"first {na} pairs, full globalalign restatement one after the other on one core, "
                                                   f"{dta:.1f} s; every one equals the GPU's alignment"}
-                print(json.dumps(line), flush=True)
-                return
+                return line
             rc, sc, ei, ej = orc.sw_score_batch(pool, ox[:ns], lx[:ns], oy[:ns], ly[:ns], "protein", threads=threads)
             dtc = time.perf_counter() - t1
             assert rc == 0 and np.array_equal(sc, out[0][:ns]) and np.array_equal(ei, out[1][:ns]) and np.array_equal(ej, out[2][:ns])
@@ -213,14 +247,24 @@ def bench_batch(args, rank, local_rank, world, dist, torch):
                 line["cpu_baseline"] = {"value": round(na / dta, 1), "unit": "pairs/s", "cores": 1, "kind": "port",
                                         "sample": f"first {na} pairs, full localalign (fill, prefix refill, traceback) one after the other "
                                                   f"on one core, {dta:.1f} s; sampled alignments equal the GPU's"}
-                print(json.dumps(line), flush=True)
-                return
+                return line
             line["cpu_baseline"] = {"value": round(ns / dtc, 1), "unit": "pairs/s", "cores": threads, "kind": "port",
                                     "sample": f"first {ns} pairs, one pair per thread on {threads} threads, {dtc:.1f} s; results equal the GPU's"}
-        print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    eng.close()
+    return line
+
+
+def batch_pmc_traffic(workload, per_rank):
+    """HBM bytes per call of the batch kernels from the committed PMC passes (profiles/r02_batch_pmc.json), scaled
+    by the number of pairs (the traffic is per pair: sequences in, descriptors in, results out); null when there
+    is no profile for the workload."""
+    f = Path(__file__).resolve().parent / "profiles" / "r02_batch_pmc.json"
+    if not f.exists():
+        return None
+    d = json.loads(f.read_text()).get(workload)
+    if not d:
+        return None
+    return round(d["hbm_traffic_bytes_per_call"] * per_rank / d["pairs"])
 
 
 def pmc_traffic(args, m, n, world, res):
@@ -233,25 +277,66 @@ def pmc_traffic(args, m, n, world, res):
     return json.loads(f.read_text())["derived"]["hbm_traffic_bytes_per_launch"]
 
 
+def launch_check(args, rank, world):
+    """`--launch-check`: no GPU work -- every rank joins a gloo group and reports; rank 0 prints which ranks it saw.
+    What the CPU test of the launcher runs (tests/test_bench_launcher.py)."""
+    import torch
+    import torch.distributed as dist
+
+    seen = [rank]
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(t, torch.tensor([rank], dtype=torch.int64))
+        seen = sorted(int(v.item()) for v in t)
+        ranks = dist.get_world_size()
+    else:
+        ranks = 1
+    if ranks != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but {ranks} ranks joined")
+    print(f"LAUNCH_CHECK rank {rank} of {world} pid {os.getpid()} GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}", flush=True)
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": args.gpus, "rccl_ranks": ranks, "ranks_reported": seen,
+                          "backend": "gloo (launch check only; measurements use nccl = RCCL)"}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks, one per GPU (default: WORLD_SIZE if started by torch.distributed.run, else 1)")
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--size", type=int, default=1_000_000, help="query length (target is the mutated copy, ~same length)")
     ap.add_argument("--kind", default="nw", choices=["nw", "lcs", "sw"])
     ap.add_argument("--workload", default="pair", choices=["pair", "batch", "batch-align", "batch-global"],
-                    help="pair: one long pair (headline); batch: config 5, many protein pairs, SW score + end cell")
+                    help="pair: one long pair (headline) + a nested config-5 batch object; batch*: config 5 alone")
     ap.add_argument("--pairs", type=int, default=1_000_000)
     ap.add_argument("--cpu-sample", type=int, default=40000)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-batch", action="store_true", help="pair workload: leave the nested config-5 object out")
+    ap.add_argument("--launch-check", action="store_true", help="start the ranks, let each report over gloo, no GPU work")
     ap.add_argument("--unrelated", action="store_true",
                     help="SURVEY 8d config 3 variant: independent uniform y (seed 5678) instead of the ~90 %% identity pair")
     args = ap.parse_args()
 
+    in_launcher = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus is None:
+        args.gpus = int(os.environ["WORLD_SIZE"]) if in_launcher else 1
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and not in_launcher:
+        # nothing above imported torch or touched HIP: the ranks are a child process
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but torch.distributed.run started {world} ranks")
+    if args.launch_check:
+        return launch_check(args, rank, world)
 
     import torch
 
@@ -260,19 +345,32 @@ def main():
 
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the process group has {dist.get_world_size()} ranks")
     else:
         dist = None
+    rccl_ranks = dist.get_world_size() if dist is not None else 1
+
+    def finish():
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
 
     import sequencealigner_amd as sa
     from sequencealigner_amd.synth import dna_pair
 
     if args.workload in ("batch", "batch-align", "batch-global"):
-        return bench_batch(args, rank, local_rank, world, dist, torch)
+        line = bench_batch(args, rank, local_rank, world, dist, torch)
+        if rank == 0:
+            line["rccl_ranks"] = rccl_ranks
+            print(json.dumps(line), flush=True)
+        return finish()
 
     x, y = dna_pair(args.size, seed=5678, related=False) if args.unrelated else dna_pair(args.size, seed=1234)
     m, n = len(x), len(y)
     cells = m * n
 
+    eng = None
     if world > 1:
         from sequencealigner_amd.stripes import StripedAligner
 
@@ -312,29 +410,46 @@ def main():
     tb_ms = 0.0
     dev_ms = 0.0
     launches = 0
+    cells_trace = cells_notrace = 0
     for _ in range(args.steps):
         res = run()
         dev_ms += res.fill_ms + res.traceback_ms
         kernel_ms += res.kernel_fill_ms
         tb_ms += res.traceback_ms
         launches += res.n_launches
+        cells_trace += res.cells_trace
+        cells_notrace += res.cells_notrace
     sync()
     dt = time.perf_counter() - t0
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+        # per-rank kernel time and cell counts: the roofline is per GPU, so sum the work and take the longest kernel
+        kk = torch.tensor([kernel_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(kk, op=dist.ReduceOp.MAX)
+        kernel_ms = float(kk.item())
+        cc = torch.tensor([float(cells_trace), float(cells_notrace)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(cc, op=dist.ReduceOp.SUM)
+        cells_trace, cells_notrace = int(cc[0].item()), int(cc[1].item())
 
+    line = None
     if rank == 0:
         gcups = cells * args.steps / dt / 1e9
         k_s = kernel_ms / 1e3
         ops = OPS_PER_CELL[args.kind]
-        achieved = cells * args.steps * ops / k_s / 1e12 / world  # per GPU
+        ops_nt = ops - OPS_CODE[args.kind]
+        # every fill launch is inside kernel_ms (a checkpointed run: the code-free checkpoint pass + the bands
+        # recomputed during the traceback) and every cell is counted at the work its launch does
+        lane_ops = cells_trace * ops + cells_notrace * ops_nt
+        achieved = lane_ops / k_s / 1e12 / world  # per GPU
+        hbm_bytes = cells_trace * HBM_BYTES_PER_CELL
         line = {
             "metric": "GCUPS NW fill+traceback (cell updates/s)" if args.kind == "nw" else f"GCUPS {args.kind} fill+traceback",
             "value": round(gcups, 2),
             "unit": "GCUPS",
             "n_gpus": world,
+            "rccl_ranks": rccl_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
@@ -370,16 +485,18 @@ def main():
                 "unit": "T int32 lane-ops/s",
                 "frac": round(achieved / VALU_PEAK_TOPS, 4),
                 "traffic": pmc_traffic(args, m, n, world, res),
-                "traffic_note": "HBM bytes per launch, WRITE_SIZE + 2 x FETCH_SIZE of profiles/r01_nw1m_pmc_v5_persistent.json; "
+                "traffic_note": "HBM bytes per launch, WRITE_SIZE + 2 x FETCH_SIZE of the PMC passes under profiles/; "
                                 "algorithmic: 0.25 B/cell trace + 16 B per strip column of bottom-row hand-off",
                 "kernel": "fill_persistent" if res.n_launches < 100 else "fill_tile",
                 "ops_per_cell": ops,
+                "ops_per_cell_code_free_pass": ops_nt,
+                "cells_per_step": {"with_codes": cells_trace // args.steps, "code_free": cells_notrace // args.steps},
                 "avg_launch_us": round(kernel_ms * 1e3 / max(launches, 1), 2),
                 "hbm": {
-                    "achieved": round(cells * args.steps * HBM_BYTES_PER_CELL / k_s / 1e9 / world, 1),
+                    "achieved": round(hbm_bytes / k_s / 1e9 / world, 1),
                     "peak": HBM_PEAK_GBS,
                     "unit": "GB/s",
-                    "frac": round(cells * args.steps * HBM_BYTES_PER_CELL / k_s / 1e9 / world / HBM_PEAK_GBS, 4),
+                    "frac": round(hbm_bytes / k_s / 1e9 / world / HBM_PEAK_GBS, 4),
                     "bytes_per_cell": HBM_BYTES_PER_CELL,
                 },
             },
@@ -393,10 +510,23 @@ def main():
                 rb["port"] = {"value": cb["value"], "sample": cb["sample"]}
                 cb = rb
             line["cpu_baseline"] = cb
+
+    if not args.no_batch:
+        # the other half of BASELINE.json's metric, same run: config 5 sharded over the same ranks.  The pair's
+        # workspaces (250 GB of codes at 1 Mb x 1 Mb) go first.
+        if eng is not None:
+            eng.close()
+        else:
+            runner.engine.eng.release_workspace()
+        sync()
+        bl = bench_batch(args, rank, local_rank, world, dist, torch, workload="batch", nested=True)
+        if rank == 0:
+            line["batch"] = {k: bl[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "config", "value_note",
+                                                "value_host_pool", "value_host_pool_note", "gcups_end_to_end", "gcups_kernel_only",
+                                                "roofline", "cpu_baseline") if k in bl}
+    if rank == 0:
         print(json.dumps(line), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish()
 
 
 if __name__ == "__main__":

@@ -63,7 +63,7 @@ typedef struct {
   double gap_open;       /* negative; added as int+double and truncated per op (main.cpp:603) */
   double gap_extend;
   const int8_t* sub;     /* alpha x alpha substitution scores, row-major, sub[ix*alpha+iy] */
-  int32_t alpha;         /* <= 32 */
+  int32_t alpha;         /* <= 32 (the many-pair entry points: <= 31, one symbol is their padding) */
   const uint8_t* idx256; /* residue byte -> table index, 255 = invalid (the reference throws) */
 } sa_scoring;
 
@@ -82,6 +82,11 @@ typedef struct {
   int32_t n_launches;       /* fill kernel launches */
   int32_t rows_per_lane;    /* K chosen for this call */
   int32_t tile_steps;       /* C chosen for this call */
+  /* cells computed by the fill launches counted in kernel_fill_ms, by the work done per cell: with direction
+   * codes (the normal fill; the bands a checkpointed traceback recomputes) / without (score-only calls, the
+   * checkpoint pass).  A checkpointed call has cells_notrace = m*n and cells_trace = the recomputed cells;
+   * its band launches are counted in fill_ms / kernel_fill_ms, not in traceback_ms. */
+  int64_t cells_trace, cells_notrace;
 } sa_result;
 
 /* ---- lifetime ---- */

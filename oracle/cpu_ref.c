@@ -771,6 +771,86 @@ int orc_nw_banded(const uint8_t* x, int64_t m, const uint8_t* y, int64_t n, int 
   return rc;
 }
 
+/* Banded LCS (main.cpp:1575-1592 fill, :1602-1635 traceback) for sizes the full oracle cannot reach: row i
+ * covers columns [lo_i, hi_i] around c_i = i*n/m as in orc_nw_banded.  L is monotone in i and in j, so a cell
+ * outside the band is replaced by a LOWER bound of its true value: to the right of the previous row's band the
+ * last value inside it, to the left of the current row's band the (older) value the row buffer still holds.
+ * In-band values are therefore lower bounds of the true ones, and the result is exact whenever the
+ * reference's traceback path stays inside the band (reported through *touched_edge as in orc_nw_banded;
+ * tests/test_oracle_golden.py checks it against orc_lcs at sizes both can run). */
+int orc_lcs_banded(const uint8_t* x, int64_t m, const uint8_t* y, int64_t n, int64_t band, orc_result* out,
+                   int* touched_edge) {
+  memset(out, 0, sizeof *out);
+  *touched_edge = 0;
+  size_t bw = (size_t)(2 * band + 1);
+  size_t w = (size_t)n + 2;
+  uint64_t* T = (uint64_t*)calloc(((size_t)(m + 1) * bw + 31) / 32, sizeof(uint64_t));
+  int* L = (int*)calloc(2 * w, sizeof(int));
+  if (!T || !L) {
+    free(T);
+    free(L);
+    return ORC_ERR_NOMEM;
+  }
+#define CTR(i) ((m) ? (int64_t)((__int128)(i) * n / m) : 0)
+#define LO(i) (CTR(i) - band < 0 ? 0 : CTR(i) - band)
+#define HI(i) (CTR(i) + band > n ? n : CTR(i) + band)
+  for (int64_t i = 1; i <= m; ++i) {
+    int* up = L + (size_t)((i - 1) & 1) * w;
+    int* cur = L + (size_t)(i & 1) * w;
+    int64_t lo = LO(i), hi = HI(i), phi = HI(i - 1);
+    size_t base = (size_t)i * bw;
+    for (int64_t j = phi + 1; j <= hi; ++j) up[j] = up[phi]; /* right of the previous row's band */
+    if (lo == 0)
+      cur[0] = 0;
+    else if (cur[lo - 1] < up[lo - 1])
+      cur[lo - 1] = up[lo - 1]; /* L[i][lo-1] >= L[i-1][lo-1] */
+    for (int64_t j = (lo == 0 ? 1 : lo); j <= hi; ++j) {
+      unsigned code;
+      if (x[i - 1] == y[j - 1]) {
+        cur[j] = up[j - 1] + 1;
+        code = 0; /* 'D' */
+      } else if (up[j] >= cur[j - 1]) {
+        cur[j] = up[j];
+        code = 2; /* 'U' */
+      } else {
+        cur[j] = cur[j - 1];
+        code = 1; /* 'L' */
+      }
+      put2(T, base + (size_t)(j - lo), code);
+    }
+  }
+  out->score = m ? L[(size_t)(m & 1) * w + n] : 0;
+  int64_t ci = m, cj = n, cap = 0;
+  out->end_i = m;
+  out->end_j = n;
+  while (ci > 0 && cj > 0) {
+    int64_t lo = LO(ci), hi = HI(ci);
+    if ((lo > 0 && cj <= lo + 1) || (hi < n && cj >= hi - 1)) *touched_edge = 1;
+    if (cj < lo || cj > hi) {
+      *touched_edge = 2;
+      break;
+    }
+    unsigned c = get2(T, (size_t)ci * bw + (size_t)(cj - lo));
+    ops_push(&out->ops, &out->n_ops, &cap, (uint8_t)c);
+    if (c == 0)
+      --ci, --cj;
+    else if (c == 1)
+      --cj;
+    else
+      --ci;
+  }
+  if (*touched_edge != 2) {
+    while (ci > 0) ops_push(&out->ops, &out->n_ops, &cap, 2), --ci;
+    while (cj > 0) ops_push(&out->ops, &out->n_ops, &cap, 1), --cj;
+  }
+#undef CTR
+#undef LO
+#undef HI
+  free(T);
+  free(L);
+  return ORC_OK;
+}
+
 /* -------------------------------------------------------------- stripes --- */
 
 struct orc_stripe {

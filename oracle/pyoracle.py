@@ -86,6 +86,8 @@ class Oracle:
         L.orc_lcs_packed.argtypes = [p8, C.c_int64, p8, C.c_int64, C.POINTER(_Res)]
         L.orc_nw_banded.argtypes = [p8, C.c_int64, p8, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_int64,
                                     C.POINTER(_Res), C.POINTER(C.c_int)]
+        L.orc_lcs_banded.argtypes = [p8, C.c_int64, p8, C.c_int64, C.c_int64, C.POINTER(_Res), C.POINTER(C.c_int)]
+        L.orc_lcs_banded.restype = C.c_int
         L.orc_sw_score.argtypes = [p8, C.c_int64, p8, C.c_int64, C.c_int, C.c_double, C.c_double,
                                    C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.orc_sw_score_batch.argtypes = [p8, p8, p8, p8, p8, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_int,
@@ -154,6 +156,13 @@ class Oracle:
         touched = C.c_int(0)
         rc = self.lib.orc_nw_banded(x.ctypes.data, len(x), y.ctypes.data, len(y), MODE[mode], go, ge, band,
                                     C.byref(r), C.byref(touched))
+        return self._wrap(rc, r, len(x), len(y), False), touched.value
+
+    def lcs_banded(self, x, y, band):
+        x, y = _u8(x), _u8(y)
+        r = _Res()
+        touched = C.c_int(0)
+        rc = self.lib.orc_lcs_banded(x.ctypes.data, len(x), y.ctypes.data, len(y), band, C.byref(r), C.byref(touched))
         return self._wrap(rc, r, len(x), len(y), False), touched.value
 
     def sw_score(self, x, y, mode="protein", go=-5.0, ge=-1.0):

@@ -42,7 +42,7 @@ struct sa_ctx {
   hipStream_t copy_stream = nullptr;  // batch alignments: a chunk's moves leave the device while the next chunk computes
   hipEvent_t ev_chunk = nullptr;
   hipStream_t stream = nullptr;
-  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // [4]: stripe flags reset
+  hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // [4]: stripe flags reset; [5], [6]: around a recomputed band
   std::string err;
   int force_K = 0, force_C = 0;
   size_t batch_trace_budget = (size_t)32 << 30;  // sa_sw_batch_align: device bytes of direction codes per chunk
@@ -359,6 +359,16 @@ int check_scoring(sa_ctx* ctx, int kind, const sa_scoring* sc, int64_t m, int64_
   if (smax > 31) return fail(ctx, SA_ERR_UNSUPPORTED, "substitution scores beyond +-31 do not fit the int8 tagged profile");
   const double worst = ((double)m + n_total + 2) * std::max({std::fabs(sc->gap_open) + 1, std::fabs(sc->gap_extend) + 1, (double)smax});
   if (worst > 1.2e8) return fail(ctx, SA_ERR_ARG, "score range would overflow the 4x-scaled int32 arithmetic");
+  return SA_OK;
+}
+
+// The batch kernels hold 4x-scaled int32 values for pairs of at most kBatchMaxM x kBatchMaxN cells: the same worst-case
+// bound as check_scoring, on those limits (e.g. H[i][0] = 4 go + (i-1) 4 max(go, ge) in nw_batch_kernel).
+int check_batch_scoring(sa_ctx* ctx, const sa_scoring* sc) {
+  int smax = 0;
+  for (int i = 0; i < sc->alpha * sc->alpha; ++i) smax = std::max(smax, std::abs((int)sc->sub[i]));
+  const double worst = ((double)kBatchMaxM + kBatchMaxN + 2) * std::max({std::fabs(sc->gap_open) + 1, std::fabs(sc->gap_extend) + 1, (double)smax});
+  if (worst > 1.2e8) return fail(ctx, SA_ERR_ARG, "gap penalties of this size would overflow the batch kernels' 4x-scaled int32 arithmetic");
   return SA_OK;
 }
 
@@ -694,6 +704,8 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   ctx->last.args = a;
   ctx->last.lds = lds;
   ctx->last.lprof = lprof;
+  // cells this fill computed, by the work done per cell (with / without direction codes)
+  (a.trace ? out->cells_trace : out->cells_notrace) = (int64_t)m * n;
   return SA_OK;
 }
 
@@ -736,13 +748,16 @@ int traceback_ckpt(sa_ctx* ctx, int start_i, int start_j, sa_result* out) {
     a.s_last = s_hi;
     a.trace_s0 = s_lo;
     const dim3 grid(std::min((s_hi - s_lo + 1 + kWavesPerBlock - 1) / kWavesPerBlock, ctx->n_cu * std::max(1, ctx->wps)));
+    HIPCK(ctx, hipEventRecord(ctx->ev[5], st));
     if (kind == KIND_NW)
       launch_persistent<KIND_NW>(K, grid, ctx->last.lds, st, a);
     else if (kind == KIND_SW)
       launch_persistent<KIND_SW>(K, grid, ctx->last.lds, st, a);
     else
       launch_persistent<KIND_LCS>(K, grid, ctx->last.lds, st, a, false, ctx->last.lprof != 0);
+    HIPCK(ctx, hipEventRecord(ctx->ev[6], st));
     ++out->n_launches;
+    out->cells_trace += (int64_t)(std::min<int64_t>(m, (int64_t)(s_hi + 1) * 64 * K) - (int64_t)s_lo * 64 * K) * n;
     TraceArgs t{};
     t.kind = kind;
     t.m = m;
@@ -767,6 +782,9 @@ int traceback_ckpt(sa_ctx* ctx, int start_i, int start_j, sa_result* out) {
     HIPCK(ctx, hipMemcpyAsync(&h_err, d_err, 4, hipMemcpyDeviceToHost, st));
     HIPCK(ctx, hipStreamSynchronize(st));
     if (h_err) return fail(ctx, SA_ERR_HIP, "persistent fill (band %d..%d): a bounded wait expired (results discarded)", s_lo, s_hi);
+    float t_band = 0;
+    HIPCK(ctx, hipEventElapsedTime(&t_band, ctx->ev[5], ctx->ev[6]));
+    out->kernel_fill_ms += t_band;  // run_pair adds the checkpoint pass and takes the bands out of traceback_ms
     nops = h_hdr[0];
     const int ni = (int)h_hdr[3], nj = (int)h_hdr[4];
     const bool handover = ni == t.i_min && ni > 0 && nj > 0 && ni < i;
@@ -911,9 +929,12 @@ int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t
     HIPCK(ctx, hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]));
     HIPCK(ctx, hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]));
     HIPCK(ctx, hipEventElapsedTime(&t23, ctx->ev[2], ctx->ev[3]));
-    out->fill_ms = t01 + t12;
-    out->kernel_fill_ms = t12;
-    out->traceback_ms = t23;
+    // a checkpointed traceback recomputed bands of codes: their launches are fill work (traceback_ckpt summed them
+    // into kernel_fill_ms), so that kernel_fill_ms covers EVERY fill launch of the call
+    const float t_bands = out->kernel_fill_ms;
+    out->fill_ms = t01 + t12 + t_bands;
+    out->kernel_fill_ms = t12 + t_bands;
+    out->traceback_ms = t23 - t_bands;
   }
   if (dump) {  // borders of the dumped matrix (the kernel writes interior cells only)
     const size_t w = (size_t)n + 1;
@@ -1169,6 +1190,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     return fail(ctx, SA_ERR_UNSUPPORTED, "fractional gap penalties are not implemented on the batch path");
   if (sc->gap_open > 0 || sc->gap_extend > 0 || sc->gap_open < -1e6 || sc->gap_extend < -1e6)
     return fail(ctx, SA_ERR_ARG, "batch path needs non-positive gap penalties");
+  if (int rcs = check_batch_scoring(ctx, sc)) return rcs;
   if (n_pairs == 0) return SA_OK;
   if (n_pairs > 0x7fffff00LL) return fail(ctx, SA_ERR_ARG, "too many pairs");
   HIPCK(ctx, hipSetDevice(ctx->device));
@@ -1511,6 +1533,7 @@ sa_ctx* sa_create(int device_id) {
       delete c;
       return nullptr;
     }
+  c->err.reserve(512);
   return c;
 }
 

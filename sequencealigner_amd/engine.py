@@ -65,6 +65,8 @@ class _Result(C.Structure):
         ("n_launches", C.c_int32),
         ("rows_per_lane", C.c_int32),
         ("tile_steps", C.c_int32),
+        ("cells_trace", C.c_int64),
+        ("cells_notrace", C.c_int64),
     ]
 
 
@@ -103,6 +105,8 @@ class AlignResult:
     n_launches: int = 0
     rows_per_lane: int = 0
     tile_steps: int = 0
+    cells_trace: int = 0
+    cells_notrace: int = 0
     extra: dict = field(default_factory=dict)
 
 
@@ -227,7 +231,8 @@ class Engine:
         if keep_dp and r.dp:
             dp = np.ctypeslib.as_array(r.dp, shape=(m + 1, n + 1)).copy()
         out = AlignResult(int(r.score), (int(r.end_i), int(r.end_j)), (int(r.start_i), int(r.start_j)), ops, dp,
-                          r.fill_ms, r.traceback_ms, r.kernel_fill_ms, r.n_launches, r.rows_per_lane, r.tile_steps)
+                          r.fill_ms, r.traceback_ms, r.kernel_fill_ms, r.n_launches, r.rows_per_lane, r.tile_steps,
+                          int(r.cells_trace), int(r.cells_notrace))
         self.lib.sa_free_result(C.byref(r))
         return out
 
@@ -316,7 +321,8 @@ class Engine:
         if rc:
             raise SeqAlignError(rc, self.lib.sa_last_error(self.ctx).decode())
 
-    def sw_batch(self, seqs, off_x, len_x, off_y, len_y, mode="protein", gap_open=-5.0, gap_extend=-1.0, sub=None, idx256=None):
+    def sw_batch(self, seqs, off_x, len_x, off_y, len_y, mode="protein", gap_open=-5.0, gap_extend=-1.0, sub=None, idx256=None,
+                 _fn="sa_sw_batch"):
         seqs = _u8(seqs)
         off_x = np.ascontiguousarray(off_x, np.int64)
         off_y = np.ascontiguousarray(off_y, np.int64)
@@ -328,9 +334,9 @@ class Engine:
         ej = np.zeros(n, np.int32)
         sc, keep = self._scoring(mode, gap_open, gap_extend, sub, idx256)
         ms = C.c_float(0)
-        rc = self.lib.sa_sw_batch(self.ctx, seqs.ctypes.data, off_x.ctypes.data, len_x.ctypes.data, off_y.ctypes.data,
-                                  len_y.ctypes.data, n, C.byref(sc), score.ctypes.data, ei.ctypes.data, ej.ctypes.data,
-                                  C.byref(ms))
+        rc = getattr(self.lib, _fn)(self.ctx, seqs.ctypes.data, off_x.ctypes.data, len_x.ctypes.data, off_y.ctypes.data,
+                                    len_y.ctypes.data, n, C.byref(sc), score.ctypes.data, ei.ctypes.data, ej.ctypes.data,
+                                    C.byref(ms))
         if rc and rc != SA_ERR_INVALID_CODE:
             raise SeqAlignError(rc, self.lib.sa_last_error(self.ctx).decode())
         return score, ei, ej, ms.value, rc

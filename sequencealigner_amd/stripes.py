@@ -222,6 +222,7 @@ class StripedAligner:
         out = AlignResult(int(score.item()), (m, n), (0, 0), ops)
         out.fill_ms, out.kernel_fill_ms, out.traceback_ms = res.fill_ms, res.kernel_fill_ms, tb.traceback_ms
         out.n_launches, out.rows_per_lane, out.tile_steps = res.n_launches, res.rows_per_lane, res.tile_steps
+        out.cells_trace, out.cells_notrace = getattr(res, "cells_trace", 0), getattr(res, "cells_notrace", 0)
         out.extra = {"stripe": (c0, c1), "stripe_ops": len(tb.ops)}
         return out
 
@@ -286,6 +287,7 @@ class StripedAligner:
         out = AlignResult(score, (bi, bj), tuple(int(v) for v in st.tolist()), all_ops)
         out.fill_ms, out.kernel_fill_ms, out.traceback_ms = res.fill_ms, res.kernel_fill_ms, tb_ms
         out.n_launches, out.rows_per_lane, out.tile_steps = res.n_launches, res.rows_per_lane, res.tile_steps
+        out.cells_trace, out.cells_notrace = getattr(res, "cells_trace", 0), getattr(res, "cells_notrace", 0)
         out.extra = {"stripe": (c0, c0 + ng), "stripe_ops": len(ops), "owner": owner}
         return out
 

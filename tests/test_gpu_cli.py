@@ -40,6 +40,27 @@ def test_cli_big_dna3_dna4(tmp_path):
     check_files(tmp_path, c["files"], GLOBAL_FILES)
 
 
+@pytest.mark.parametrize("case", ["synth100k_related", "synth100k_unrelated"])
+def test_cli_config3_100k_equals_reference(tmp_path, case):
+    """Config 3 at its own size against the reference ITSELF: it ran these two synthetic 100 000 x ~100 000 pairs in the
+    build container (50 GB each; tests/golden/make_golden_100k.py), the ~90 %-identity one (seed 1234) and the unrelated
+    one (seed 5678, gap-dense path, ties everywhere).  Score, alignment and path files byte for byte."""
+    from make_golden_shared import write_fasta
+    from sequencealigner_amd.synth import dna_pair
+
+    c = {x["id"]: x for x in json.loads((GOLD / "big100k.json").read_text())}[case]
+    g = c["synth"]
+    x, y = dna_pair(g["n"], seed=g["seed"], related=g["related"])
+    assert (len(x), len(y)) == (c["m"], c["n"])
+    write_fasta(tmp_path / "q.fasta", "seqA synth", x.tobytes().decode())
+    write_fasta(tmp_path / "t.fasta", "seqB synth", y.tobytes().decode())
+    out = tmp_path / "o"
+    r = subprocess.run([str(PKG / "aligner"), "--query", str(tmp_path / "q.fasta"), "--target", str(tmp_path / "t.fasta"),
+                        "--choice", "1", "--mode", "dna", "--outdir", str(out)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stderr == "", r.stderr
+    check_files(out, c["files"], GLOBAL_FILES)
+
+
 def test_cli_dp_dumps_match_reference_layout(tmp_path):
     """--txt / --binary dumps (main.cpp:422-528): compared against files built from the oracle's
     matrices through the same writers is circular, so the format is pinned by hand here and

@@ -5,8 +5,14 @@ the full oracle can run.  Size-independent checks:
     edge, which the oracle reports), ~30 s of host time;
   * the two independent fill schedules (persistent pipeline / per-diagonal launches) agree bit
     for bit;
-  * LCS: the op list is a valid common subsequence walk whose diagonal moves all match and whose
-    length is the reported score, it consumes exactly m and n residues, and both schedules agree.
+  * LCS: score AND the complete op list equal the banded LCS oracle's (orc_lcs_banded, validated against the
+    full orc_lcs in tests/test_oracle_golden.py), which pins optimality and the reference's up-over-left
+    tie-break at full size; besides, the op list is a valid common subsequence walk whose diagonal moves
+    all match and whose length is the reported score, and both schedules agree;
+  * the checkpointed runs (codes recomputed band by band) equal the banded oracle too, not only the
+    one-slab GPU run.
+The banded NW oracle itself reproduces the reference's own files for the 100 000 x 100 085 pair
+(tests/test_oracle_golden.py::test_banded_oracle_matches_reference_at_100k).
 """
 import numpy as np
 import pytest
@@ -21,10 +27,18 @@ def pair_1mb():
     return dna_pair(1_000_000, seed=1234)
 
 
-def test_nw_1mb_equals_banded_oracle_and_both_schedules(engine, oracle, pair_1mb):
-    x, y = pair_1mb
-    want, touched = oracle.nw_banded(x, y, 1024, "dna")
+@pytest.fixture(scope="module")
+def nw_1mb_want(pair_1mb):
+    from oracle import Oracle
+
+    want, touched = Oracle().nw_banded(*pair_1mb, 1024, "dna")
     assert want.rc == 0 and touched == 0
+    return want
+
+
+def test_nw_1mb_equals_banded_oracle_and_both_schedules(engine, nw_1mb_want, pair_1mb):
+    x, y = pair_1mb
+    want = nw_1mb_want
     engine.set_option("persistent", 1)
     a = engine.nw(x, y, "dna")
     assert a.n_launches == 1
@@ -36,10 +50,14 @@ def test_nw_1mb_equals_banded_oracle_and_both_schedules(engine, oracle, pair_1mb
     assert b.score == a.score and np.array_equal(a.ops, b.ops)
 
 
-def test_lcs_1mb_properties(engine, pair_1mb):
+def test_lcs_1mb_equals_banded_oracle(engine, oracle, pair_1mb):
     x, y = pair_1mb
     engine.set_option("persistent", 1)
     a = engine.lcs(x, y)
+    want, touched = oracle.lcs_banded(x, y, 1024)
+    assert want.rc == 0 and touched == 0
+    assert a.score == want.score
+    assert len(a.ops) == len(want.ops) and np.array_equal(a.ops, want.ops)
     ops = a.ops
     takes_x, takes_y = ops != 1, ops != 2
     assert int(takes_x.sum()) == len(x) and int(takes_y.sum()) == len(y)
@@ -54,18 +72,21 @@ def test_lcs_1mb_properties(engine, pair_1mb):
     assert b.score == a.score and np.array_equal(a.ops, b.ops)
 
 
-def test_nw_1mb_checkpointed_bands_equal_one_slab(engine, pair_1mb):
-    """The same pair with the codes recomputed 300 strips at a time from per-strip checkpoints."""
+def test_nw_1mb_checkpointed_bands_equal_banded_oracle(engine, nw_1mb_want, pair_1mb):
+    """The same pair with the codes recomputed 300 strips at a time from per-strip checkpoints: equal to the banded
+    oracle (not only to the one-slab GPU run)."""
     x, y = pair_1mb
     engine.set_option("persistent", 1)
-    a = engine.nw(x, y, "dna")
+    a = nw_1mb_want
     engine.set_option("checkpoint_band", 300)
     try:
         b = engine.nw(x, y, "dna")
     finally:
         engine.set_option("checkpoint_band", 0)
     assert b.n_launches == 1 + 7  # 1954 strips of 512 rows: one checkpoint pass + 7 bands
-    assert b.score == a.score and np.array_equal(a.ops, b.ops)
+    assert b.score == a.score and len(a.ops) == len(b.ops) and np.array_equal(a.ops, b.ops)
+    # every fill launch is accounted for: the code-free pass over all cells + the recomputed bands
+    assert b.cells_notrace == len(x) * len(y) and 0 < b.cells_trace <= 1.01 * len(x) * len(y)
 
 
 def test_nw_2mb_beyond_device_memory(engine, oracle):
