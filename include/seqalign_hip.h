@@ -137,6 +137,25 @@ int sa_sw_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const in
                 const sa_scoring* sc, int32_t* score, int32_t* end_i, int32_t* end_j,
                 float* kernel_ms);
 
+/* sa_sw_batch for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same inputs, outputs, kernels and results as sa_sw_batch,
+ * but the call allocates nothing: no hipMalloc / hipFree / hipHostMalloc and no host containers.  Its device
+ * scratch (sequence staging, pair descriptors, per-pair results, error flag, scoring tables) is one file-scope
+ * `static __device__` array of SA_NOALLOC_MAX_SEQ_BYTES + 48 + 12 bytes per pair of SA_NOALLOC_MAX_PAIRS + 2 KiB
+ * (33 MiB) that every GPU the library runs on holds until the process ends; sa_create() looks its address up once per device and pins the
+ * 1 MB host staging block the call uses.  Limits, rejected with SA_ERR_ARG / SA_ERR_UNSUPPORTED and a message:
+ * n_pairs <= SA_NOALLOC_MAX_PAIRS; unless a device pool is set (sa_batch_set_device_pool: the sequences are then read
+ * in place), every pair must end within the first SA_NOALLOC_MAX_SEQ_BYTES of `seqs`; every pair must fit the batch
+ * kernels (len_x <= 1024, len_y <= 3895: sa_sw_batch's single-pair fallback allocates and is not taken).
+ * All calls on one GPU (from any ctx) share that GPU's array, which keeps the last call's contents (the call clears
+ * what must start at zero): calls that overlap in time on one GPU race. */
+#define SA_NOALLOC_MAX_PAIRS 16384
+#define SA_NOALLOC_MAX_SEQ_BYTES (32 << 20)
+int sa_sw_batch_noalloc(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x,
+                        const int64_t* off_y, const int32_t* len_y, int64_t n_pairs,
+                        const sa_scoring* sc, int32_t* score, int32_t* end_i, int32_t* end_j,
+                        float* kernel_ms);
+
 /* Sequence pool already in device memory (a caller that produced or staged the sequences on the GPU, e.g. a
  * torch tensor): while a pool is set, every batch entry point below reads pair k at d_seqs + off_x[k] /
  * off_y[k], ignores its `seqs` argument (NULL is fine) and copies nothing host -> device but the pair

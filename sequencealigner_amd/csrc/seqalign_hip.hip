@@ -23,6 +23,26 @@
 
 using namespace sa;
 
+// ---- sa_sw_batch_noalloc: the one entry point that allocates nothing ----------------------------
+// Its device scratch (sequence staging, pair descriptors, per-pair results, error flag, scoring tables) is
+// this file-scope array instead of the ctx's hipMalloc'ed workspaces.  Every GPU the library is loaded on
+// holds its own copy at its own address until the process ends.  In host code the NAME of the array is
+// only a handle: the device address comes from hipGetSymbolAddress, once per device (na_scratch_for_device,
+// called by sa_create with that device current), and only that pointer is ever handed to kernels, memsets
+// and copies.
+namespace {
+constexpr size_t kNaMaxPairs = SA_NOALLOC_MAX_PAIRS;
+constexpr size_t kNaMaxSeq = SA_NOALLOC_MAX_SEQ_BYTES;
+constexpr size_t kNaDescOff = kNaMaxSeq + 256;                               // sequences first (+ slack for the kernels' reads)
+constexpr size_t kNaOutOff = kNaDescOff + kNaMaxPairs * sizeof(PairDesc);  // score | end_i | end_j, kNaMaxPairs ints each
+constexpr size_t kNaErrOff = kNaOutOff + 3 * kNaMaxPairs * 4;                // 64 bytes
+constexpr size_t kNaSubOff = kNaErrOff + 64;                                 // 1024 bytes
+constexpr size_t kNaMapOff = kNaSubOff + 1024;                               // 256 bytes
+constexpr size_t kNaBytes = (kNaMapOff + 256 + 255) & ~size_t(255);
+constexpr size_t kNaHostBytes = kNaMaxPairs * sizeof(PairDesc) + 3 * kNaMaxPairs * 4 + 64;  // pinned staging per ctx
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[kNaBytes];
+
 namespace {
 
 struct Buf {
@@ -68,6 +88,9 @@ struct sa_ctx {
   } last;
   size_t trace_budget = 0;  // bytes of codes one call may hold; 0 = 88 % of the device memory
   int force_band = 0;       // > 0: always checkpoint and recompute this many strips at a time
+  // sa_sw_batch_noalloc: this device's address of `scratch` and a page-locked staging block, both set up by sa_create
+  unsigned char* na_scratch = nullptr;
+  unsigned char* na_host = nullptr;
 };
 
 namespace {
@@ -1491,6 +1514,138 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
   return SA_OK;
 }
 
+// Device address of `scratch` on the CURRENT device, looked up once per device.
+std::mutex g_na_mu;
+unsigned char* g_na_ptr[64] = {nullptr};
+hipError_t na_scratch_for_device(int dev, unsigned char** out) {
+  *out = nullptr;
+  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+  std::lock_guard<std::mutex> lk(g_na_mu);
+  if (!g_na_ptr[dev]) {
+    void* p = nullptr;
+    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return e;
+    }
+    g_na_ptr[dev] = (unsigned char*)p;
+  }
+  *out = g_na_ptr[dev];
+  return hipSuccess;
+}
+
+// sa_sw_batch with every device buffer inside `scratch` and every host buffer inside the ctx's pinned staging
+// block: no hipMalloc / hipFree / hipHostMalloc, no std::vector.  Same kernels, same results.
+int run_batch_noalloc(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x, const int64_t* off_y,
+                      const int32_t* len_y, int64_t n_pairs, const sa_scoring* sc, int32_t* score, int32_t* end_i, int32_t* end_j,
+                      float* kernel_ms) {
+  if (!ctx) return SA_ERR_ARG;
+  if (kernel_ms) *kernel_ms = 0.f;
+  if (!ctx->na_scratch || !ctx->na_host) return fail(ctx, SA_ERR_HIP, "sa_sw_batch_noalloc: the scratch array was not set up by sa_create");
+  const bool resident = ctx->dev_pool != nullptr;
+  if (n_pairs < 0 || (n_pairs > 0 && ((!seqs && !resident) || !off_x || !len_x || !off_y || !len_y || !score || !end_i || !end_j)))
+    return fail(ctx, SA_ERR_ARG, "bad batch arguments");
+  if (n_pairs > (int64_t)kNaMaxPairs)
+    return fail(ctx, SA_ERR_ARG, "sa_sw_batch_noalloc: %lld pairs exceed SA_NOALLOC_MAX_PAIRS = %zu (split the batch or use sa_sw_batch)",
+                (long long)n_pairs, kNaMaxPairs);
+  if (!sc || !sc->sub || !sc->idx256 || sc->alpha < 1 || sc->alpha > 31) return fail(ctx, SA_ERR_ARG, "bad scoring");
+  if (sc->gap_open != std::floor(sc->gap_open) || sc->gap_extend != std::floor(sc->gap_extend))
+    return fail(ctx, SA_ERR_UNSUPPORTED, "fractional gap penalties are not implemented on the batch path");
+  if (sc->gap_open > 0 || sc->gap_extend > 0 || sc->gap_open < -1e6 || sc->gap_extend < -1e6)
+    return fail(ctx, SA_ERR_ARG, "batch path needs non-positive gap penalties");
+  if (int rcs = check_batch_scoring(ctx, sc)) return rcs;
+  if (n_pairs == 0) return SA_OK;
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int alpha = sc->alpha;
+
+  // counting sort by rows per lane K = ceil(m / 64), big pairs first, straight into the pinned staging block
+  int group_count[18] = {0}, group_nmax[18] = {0}, group_start[18] = {0}, cur[18];
+  int64_t pool_end = 0;
+  for (int64_t k = 0; k < n_pairs; ++k) {
+    if (len_x[k] < 0 || len_y[k] < 0 || off_x[k] < 0 || off_y[k] < 0) return fail(ctx, SA_ERR_ARG, "negative offset/length in pair %lld", (long long)k);
+    pool_end = std::max(pool_end, std::max(off_x[k] + len_x[k], off_y[k] + len_y[k]));
+    if (len_x[k] == 0 || len_y[k] == 0) continue;
+    if (len_x[k] > kBatchMaxM || len_y[k] > kBatchMaxN - 200)
+      return fail(ctx, SA_ERR_UNSUPPORTED, "sa_sw_batch_noalloc: pair %lld (%d x %d) is beyond the batch kernels' %d x %d (sa_sw_batch takes it)",
+                  (long long)k, len_x[k], len_y[k], kBatchMaxM, kBatchMaxN - 200);
+    const int K = (len_x[k] + 63) / 64;
+    ++group_count[K];
+    group_nmax[K] = std::max(group_nmax[K], len_y[k]);
+  }
+  if (resident) {
+    if (pool_end > ctx->dev_pool_bytes)
+      return fail(ctx, SA_ERR_ARG, "a pair ends at byte %lld of a %lld-byte device pool", (long long)pool_end, (long long)ctx->dev_pool_bytes);
+  } else if (pool_end > (int64_t)kNaMaxSeq) {
+    return fail(ctx, SA_ERR_ARG, "sa_sw_batch_noalloc: the pairs span %lld sequence bytes, beyond SA_NOALLOC_MAX_SEQ_BYTES = %zu "
+                "(split the batch, set a device pool, or use sa_sw_batch)", (long long)pool_end, kNaMaxSeq);
+  }
+  int n_desc = 0;
+  for (int K = 16; K >= 1; --K) {
+    group_start[K] = n_desc;
+    n_desc += group_count[K];
+  }
+  for (int K = 0; K < 18; ++K) cur[K] = group_start[K];
+  PairDesc* h_desc = (PairDesc*)ctx->na_host;
+  int32_t* h_out = (int32_t*)(ctx->na_host + kNaMaxPairs * sizeof(PairDesc));
+  for (int64_t k = 0; k < n_pairs; ++k) {
+    if (len_x[k] == 0 || len_y[k] == 0) continue;
+    const int K = (len_x[k] + 63) / 64;
+    h_desc[cur[K]++] = PairDesc{off_x[k], off_y[k], len_x[k], len_y[k], (int)k, 0, 0, 0};
+  }
+
+  unsigned char* d = ctx->na_scratch;  // this device's address of `scratch`
+  int* d_score = (int*)(d + kNaOutOff);
+  int* d_ei = d_score + n_pairs;
+  int* d_ej = d_ei + n_pairs;
+  int* d_err = (int*)(d + kNaErrOff);
+  int h_err = 0;
+  if (n_desc) {
+    // the array keeps the last call's contents: the error flag must start at zero; every other word that is read
+    // back (score / end cell of the n_desc pairs) is written by this call's kernels, the rest is overwritten below
+    HIPCK(ctx, hipMemsetAsync(d_err, 0, 64, st));
+    if (!resident) HIPCK(ctx, hipMemcpyAsync(d, seqs, (size_t)pool_end, hipMemcpyHostToDevice, st));
+    HIPCK(ctx, hipMemcpyAsync(d + kNaDescOff, h_desc, (size_t)n_desc * sizeof(PairDesc), hipMemcpyHostToDevice, st));
+    HIPCK(ctx, hipMemcpyAsync(d + kNaSubOff, sc->sub, (size_t)alpha * alpha, hipMemcpyHostToDevice, st));
+    HIPCK(ctx, hipMemcpyAsync(d + kNaMapOff, sc->idx256, 256, hipMemcpyHostToDevice, st));
+    BatchArgs a{};
+    a.seqs = resident ? ctx->dev_pool : (const uint8_t*)d;
+    a.sub = (const int8_t*)(d + kNaSubOff);
+    a.idx256 = (const uint8_t*)(d + kNaMapOff);
+    a.alpha = alpha;
+    a.go = (int)sc->gap_open;
+    a.ge = (int)sc->gap_extend;
+    a.score = d_score;
+    a.end_i = d_ei;
+    a.end_j = d_ej;
+    a.err = d_err;
+    a.CB = kBatchCB;
+    HIPCK(ctx, hipEventRecord(ctx->ev[0], st));
+    for (int K = 16; K >= 1; --K) {
+      if (!group_count[K]) continue;
+      a.desc = (const PairDesc*)(d + kNaDescOff) + group_start[K];
+      a.n_desc = group_count[K];
+      a.ycap = batch_ycap(group_nmax[K]);
+      launch_batch_k(K, st, a.n_desc, alpha, a, false);
+    }
+    HIPCK(ctx, hipGetLastError());
+    HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
+    HIPCK(ctx, hipMemcpyAsync(h_out, d_score, (size_t)n_pairs * 12, hipMemcpyDeviceToHost, st));
+    HIPCK(ctx, hipMemcpyAsync(h_out + 3 * n_pairs, d_err, 4, hipMemcpyDeviceToHost, st));
+    HIPCK(ctx, hipStreamSynchronize(st));
+    if (kernel_ms) HIPCK(ctx, hipEventElapsedTime(kernel_ms, ctx->ev[0], ctx->ev[1]));
+    h_err = h_out[3 * n_pairs];
+  }
+  for (int64_t k = 0; k < n_pairs; ++k) {
+    const bool none = len_x[k] == 0 || len_y[k] == 0 || !n_desc;  // no cell: the reference's zero borders, score 0
+    score[k] = none ? 0 : h_out[k];
+    end_i[k] = none ? 0 : h_out[n_pairs + k];
+    end_j[k] = none ? 0 : h_out[2 * n_pairs + k];
+  }
+  if (h_err) return fail(ctx, SA_ERR_INVALID_CODE, "at least one pair holds a residue outside the scoring alphabet (its score is INT32_MIN)");
+  return SA_OK;
+}
+
 struct Builtin {
   int8_t sub[2][32 * 32];
   uint8_t map[2][256];
@@ -1534,6 +1689,14 @@ sa_ctx* sa_create(int device_id) {
       return nullptr;
     }
   c->err.reserve(512);
+  // sa_sw_batch_noalloc: this device's address of the scratch array (the device is current here) and the pinned
+  // staging block, so that the entry point itself never allocates.  A failure here only disables that entry point.
+  if (na_scratch_for_device(device_id, &c->na_scratch) != hipSuccess) c->na_scratch = nullptr;
+  void* hp = nullptr;
+  if (hipHostMalloc(&hp, kNaHostBytes, hipHostMallocDefault) == hipSuccess)
+    c->na_host = (unsigned char*)hp;
+  else
+    (void)hipGetLastError();
   return c;
 }
 
@@ -1546,6 +1709,7 @@ void sa_destroy(sa_ctx* c) {
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
   if (c->ev_chunk) (void)hipEventDestroy(c->ev_chunk);
+  if (c->na_host) (void)hipHostFree(c->na_host);
   delete c;
 }
 
@@ -1695,5 +1859,11 @@ int sa_nw_batch_align(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, co
 }
 
 void sa_free_pool(uint8_t* pool) { pool_release(pool); }
+
+int sa_sw_batch_noalloc(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x, const int64_t* off_y,
+                        const int32_t* len_y, int64_t n_pairs, const sa_scoring* sc, int32_t* score, int32_t* end_i,
+                        int32_t* end_j, float* kernel_ms) {
+  return run_batch_noalloc(ctx, seqs, off_x, len_x, off_y, len_y, n_pairs, sc, score, end_i, end_j, kernel_ms);
+}
 
 }  // extern "C"

@@ -152,6 +152,8 @@ def load_library() -> C.CDLL:
     L.sa_sw.argtypes = pair
     L.sa_lcs.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, C.c_uint32, C.POINTER(_Result)]
     L.sa_sw_batch.argtypes = [vp, vp, vp, vp, vp, vp, C.c_int64, C.POINTER(_Scoring), vp, vp, vp, C.POINTER(C.c_float)]
+    L.sa_sw_batch_noalloc.argtypes = L.sa_sw_batch.argtypes
+    L.sa_sw_batch_noalloc.restype = C.c_int
     L.sa_stripe_fill.argtypes = [vp, C.c_int, vp, C.c_int64, vp, C.c_int64, C.POINTER(_Scoring), C.POINTER(_StripeDesc),
                                  C.POINTER(_Result)]
     L.sa_stripe_traceback.argtypes = [vp, C.c_int64, C.c_int64, C.POINTER(_Result)]
@@ -320,6 +322,10 @@ class Engine:
         rc = self.lib.sa_batch_set_device_pool(self.ctx, data_ptr, int(nbytes))
         if rc:
             raise SeqAlignError(rc, self.lib.sa_last_error(self.ctx).decode())
+
+    def sw_batch_noalloc(self, *a, **kw):
+        """sa_sw_batch_noalloc: sw_batch through the entry point that allocates nothing (static device scratch)."""
+        return self.sw_batch(*a, _fn="sa_sw_batch_noalloc", **kw)
 
     def sw_batch(self, seqs, off_x, len_x, off_y, len_y, mode="protein", gap_open=-5.0, gap_extend=-1.0, sub=None, idx256=None,
                  _fn="sa_sw_batch"):
