@@ -135,7 +135,11 @@ void run_batch_mode(sa_ctx* ctx, const Options& o) {
     sah_accession(qs[k].header.c_str(), o.mode, a, sizeof a);
     sah_accession(ts[k].header.c_str(), o.mode, b, sizeof b);
   };
-  if (o.choice == 2 || o.choice == 4) {
+  // The many-pair kernels take integral, non-positive penalties; anything else (the reference accepts any double,
+  // main.cpp:41-43) goes pair by pair through the single-pair entry points below, for every method alike.
+  const bool batch_ok = o.gap_open == std::floor(o.gap_open) && o.gap_extend == std::floor(o.gap_extend) && o.gap_open <= 0 &&
+                        o.gap_extend <= 0 && std::fabs(o.gap_open) <= 1e4 && std::fabs(o.gap_extend) <= 1e4;
+  if ((o.choice == 2 || o.choice == 4) && batch_ok) {
     // one engine call for every pair
     std::string pool;
     std::vector<int64_t> ox(np), oy(np), ops_off(np);
@@ -193,8 +197,7 @@ void run_batch_mode(sa_ctx* ctx, const Options& o) {
     }
     sa_free_pool(ops_pool);
   }
-  if ((o.choice == 1 || o.choice == 4) && o.gap_open == std::floor(o.gap_open) && o.gap_extend == std::floor(o.gap_extend) &&
-      o.gap_open <= 0 && o.gap_extend <= 0) {
+  if ((o.choice == 1 || o.choice == 4) && batch_ok) {
     // global alignments: one engine call for every pair (integral penalties; otherwise the loop below)
     std::string pool;
     std::vector<int64_t> ox(np), oy(np), ops_off(np);
@@ -251,10 +254,8 @@ void run_batch_mode(sa_ctx* ctx, const Options& o) {
     }
     sa_free_pool(ops_pool);
   }
-  const bool global_done = (o.choice == 1 || o.choice == 4) && o.gap_open == std::floor(o.gap_open) &&
-                           o.gap_extend == std::floor(o.gap_extend) && o.gap_open <= 0 && o.gap_extend <= 0;
-  for (int which : {1, 3}) {
-    if (which == 1 && global_done) continue;
+  for (int which : {2, 1, 3}) {
+    if (which != 3 && batch_ok) continue;  // done above
     if (o.choice != which && o.choice != 4) continue;
     for (int64_t k = 0; k < np; ++k) {
       Options ok = o;

@@ -6,8 +6,8 @@
 // anti-diagonal.  The cell dependencies that cross lanes (H and F of the row above, the
 // target symbol) move one lane down per step with DPP wave_shr:1 -- they never touch
 // memory.  The strip's bottom row (H,F per column) is collected in a register that is
-// rotated with DPP wave_shl:1 and flushed coalesced every 64 steps; the strip below reads
-// it the same way.  The query profile of the strip is staged in LDS as
+// rotated with DPP wave_shl:1 and flushed coalesced every 64 steps (fill_tile) or every 16 steps
+// (fill_persistent, as self-validating records); the strip below reads it the same way.  The query profile of the strip is staged in LDS as
 // prof[symbol][lane] (one dword, or two for K=8, holding the lane's K substitution
 // scores), so a lane's read hits bank == lane whatever symbol it looks up: conflict free.
 // Direction codes are packed 2 bits/cell, 16 steps per dword, and written as one
@@ -51,9 +51,11 @@ struct FillArgs {
   const int2* lb;        // left border per matrix row i = 0..m: (H[i][0], E[i][0]) of this stripe
   int2* rb;              // optional: right border out, (H[i][n], E[i][n]) for i = 1..m (column stripes)
   int* dp;               // optional (DUMP): (m+1)x(n+1) row-major S / L matrix, interior cells
-  int* botH;             // [ring][NP]  bottom row H of strip s lives in slot wr_slot(s), index p = c+64
-  int* botF;             // [ring][NP]
-  int ring;              // 2: strips alternate between two slots; S+1: every strip keeps its own (checkpoints)
+  int* botH;             // fill_tile: [ring][NP]  bottom row H of strip s lives in slot wr_slot(s), index p = c+64
+  int* botF;             // fill_tile: [ring][NP]
+  int2* bot2;            // fill_persistent: [ring][NP] hand-off records {H | generation bit, F}, same slots and index
+  int ring;              // fill_tile: 2, strips alternate between two slots.  fill_persistent: slots of hand-off records, S+1
+                         // (every strip keeps its own: checkpoints, small inputs) or the launch's waves + 2 (see ho_store)
   int* state;            // [S][NF][64] lane state carried from tile to tile
   uint32_t* trace;       // [S][W][64][K]; unused by FLAG_NOTRACE kernels (score-only / checkpoint pass)
   int trace_s0;          // strip whose codes sit at the start of `trace` (banded recomputation)
@@ -61,26 +63,53 @@ struct FillArgs {
   int* rowbestc;         // SW: first column (0-based) attaining it
   int* score_out;        // NW/LCS: H[m][n]
   int d, s_lo, s_hi;     // launch index, first / last strip of this launch
-  // persistent strip pipeline (fill_persistent): one launch, hand-off every 64 steps
-  int* prog;             // [S] blocks of 64 steps completed per strip (zeroed before the launch)
+  // persistent strip pipeline (fill_persistent): one launch, hand-off every 16 steps
   int* ticket;           // next strip to hand out, relative to s_first (zeroed)
   int s_first, s_last;   // strips this persistent launch sweeps (the whole matrix: 0 .. S-1)
   int* err;              // set to 1 when a bounded spin ran out (zeroed)
   int spin_limit;        // polls before a waiting wave gives up
   // persistent pipeline over column stripes: borders cross GPUs while the kernel runs
+#ifdef SA_DEBUG_HANDOFF
+  long long* dbg;        // [S][4]: start clock, end clock, re-read episodes, re-reads
+#endif
   const int* rows_in;    // rows of `lb` that have arrived (raised by stripe_signal on the receive stream); null: all there
   int* chunk_done;       // [chunks] strips of border chunk k whose `rb` rows are written (stripe_wait polls it); null: no right neighbour
   int strips_per_chunk;
 };
 
-// Inter-wave hand-off of the strip bottom rows inside ONE launch (persistent kernel only).
-// Every store of the handed-off words is an agent-scope relaxed atomic store (global_store ..
-// sc1: write-through), every load of them an agent-scope relaxed atomic load (sc1: not served
-// from this CU's L1), the producer drains vmcnt before one lane raises the strip's progress
-// word the same way, and the consumer reads data only after its poll matched
-// (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads", row 1).
+// Agent-scope relaxed atomic accesses (global_load / global_store .. sc1: the store writes through to L2, the
+// load is not served from this CU's L1): flags and borders that other waves or other streams touch while a
+// kernel runs (MI355X_MICROARCH.md, "Hand-offs measured with sc1 loads").
 __device__ __forceinline__ int ld_coherent(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_coherent(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// Inter-wave hand-off of the strip bottom rows inside ONE launch (persistent kernel only): one 8-byte RECORD
+// per column, {H with a 2-bit generation in bits 31:30, F}, written by ONE 8-byte agent-scope atomic store and read
+// by ONE 8-byte atomic load, so a record is seen whole or not at all and carries its own validity: there is no
+// progress flag, no store-queue drain before a publish and no second round trip for the data behind a poll.
+// Strip s writes slot (s + 1) mod ring with generation ((s + 1) / ring) mod 3 (matrix row 0 counts as strip -1: slot 0,
+// generation 0, written by the host; every other record starts as generation 3 = "not yet written"), so what a slot
+// held before -- the records of strip s - ring -- carries the generation before it.  A reader may start polling
+// arbitrarily early, so that alone would not do (the records of strip s - 3 ring look like those of strip s); the ring
+// is therefore at least two slots longer than the launch has waves (or one slot per strip when that is fewer).
+// Strips are drawn in order and strip j cannot finish before strip j-1, so the unfinished strips are a contiguous
+// run of at most `waves` strips: while strip s is running, strip s - ring has finished -- every record of the
+// slot is that strip's or newer, and nobody still reads what strip s overwrites.
+// H is a 4x-scaled score + tag of a real cell, |H| < 2^29 (check_scoring: 4 x 1.2e8), so it survives the round trip
+// through 30 bits; F travels as it is.
+__device__ __forceinline__ void ho_store(int2* p, int h, int f, int gen) {
+  const int hp = (h & 0x3fffffff) | gen;
+  const unsigned long long v = ((unsigned long long)(uint32_t)f << 32) | (uint32_t)hp;
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int2 ho_load(const int2* p) {
+  const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return make_int2((int)(uint32_t)v, (int)(v >> 32));
+}
+__device__ __forceinline__ int ho_value(int hp) { return (int)((uint32_t)hp << 2) >> 2; }  // sign-extend bit 29
+__device__ __forceinline__ bool ho_stale(int hp, int gen) { return (uint32_t)(hp ^ gen) >= 0x40000000u; }
+__device__ __forceinline__ int ho_gen(int g) { return (int)((uint32_t)g << 30); }
+constexpr int kGenInit = (int)0xC0000000u;  // generation 3
 
 // slot of the bottom-row buffers strip s reads (the row above it; row 0 of the matrix sits in the
 // last slot) and writes
@@ -101,10 +130,6 @@ __device__ __forceinline__ int dpp_shl1_any(int src) { return __builtin_amdgcn_m
 // FLAG_LPROF (persistent LCS, at most 31 distinct bytes in the pair): the match term comes from an LDS profile
 // like the NW one (byte +6 on a match, -62 otherwise: one SDWA add) instead of a compare and a select per cell.
 enum { FLAG_FRAC = 1, FLAG_DUMP = 2, FLAG_PERSIST = 4, FLAG_NOTRACE = 8, FLAG_LPROF = 16 };
-#ifndef SA_SUB_UNROLL
-#define SA_SUB_UNROLL 4
-#endif
-constexpr int kSubUnroll = SA_SUB_UNROLL;  // 16-step sub-blocks of a 64-step block expanded in line
 
 // Workgroups are 4 independent waves (256 threads): the hardware places the 4 waves of one
 // workgroup on the 4 SIMDs of a CU, which single-wave workgroups do not guarantee -- and a wave
@@ -294,49 +319,31 @@ __device__ __forceinline__ void store_trace(uint32_t* dst, const uint32_t (&t)[K
   }
 }
 
-// loads of one block's inputs: the 64 bottom-row entries of the strip above (in-buffers) and the
+// loads of one block's inputs (fill_tile): the 64 bottom-row entries of the strip above (in-buffers) and the
 // 64 target symbols lane 0 will consume
-// RAW_Y: leave the symbol unscaled, so that nothing touches the loaded registers before use
-template <int KIND, int K, int FLAGS, bool RAW_Y = false>
+template <int KIND, int K, int FLAGS>
 __device__ __forceinline__ void load_block_inputs(const FillArgs& a, const int s, const int Tb, const int lane, int& ibH,
                                                   int& ibF, int& yb) {
   using G = Geo<KIND, K>;
-  constexpr bool PERSIST = (FLAGS & FLAG_PERSIST) != 0;
   const int* rdH = a.botH + (size_t)rd_slot(a, s) * a.NP;
   const int* rdF = a.botF + (size_t)rd_slot(a, s) * a.NP;
   ibF = 0;
-  if (PERSIST) {
-    ibH = ld_coherent(rdH + Tb + 64 + lane);
-    if (KIND != KIND_LCS) ibF = ld_coherent(rdF + Tb + 64 + lane);
-  } else {
-    ibH = rdH[Tb + 64 + lane];
-    if (KIND != KIND_LCS) ibF = rdF[Tb + 64 + lane];
-  }
+  ibH = rdH[Tb + 64 + lane];
+  if (KIND != KIND_LCS) ibF = rdF[Tb + 64 + lane];
   yb = a.yenc[Tb + lane];
-  if ((KIND != KIND_LCS || (FLAGS & FLAG_LPROF)) && !RAW_Y) yb *= G::ROWB;
+  if (KIND != KIND_LCS || (FLAGS & FLAG_LPROF)) yb *= G::ROWB;
 }
 
-struct NoHook {
-  __device__ __forceinline__ void operator()(int) const {}
-};
-
-// 64 steps of one strip (one bottom-row hand-off in, one out).  `hook(sub)` runs after each of
-// the four 16-step sub-blocks (the persistent kernel hides its polls / prefetches there).
-template <int KIND, int K, bool BND, int FLAGS, typename Hook>
+// 64 steps of one strip (fill_tile: one bottom-row hand-off in, one out)
+template <int KIND, int K, bool BND, int FLAGS>
 __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, const int s, const int Tb,
                                           const int lane, const char* ldsLane, const uint32_t (&xr)[K], int* dprow,
-                                          int ibH, int ibF, int yb, Hook&& hook) {
-  constexpr bool PERSIST = (FLAGS & FLAG_PERSIST) != 0;
-  // The persistent kernels expand the four sub-blocks in line: values prefetched in one
-  // sub-block and used in a later one then stay in their registers (a loop makes them
-  // loop-carried copies, and the compiler waits for a load before it copies its result).  For SW
-  // this fits the register file only because lane_step pins its first-maximum keys in place.
-  constexpr int kUnroll = PERSIST ? kSubUnroll : 1;
+                                          int ibH, int ibF, int yb) {
   int* wrH = a.botH + (size_t)wr_slot(a, s) * a.NP;
   int* wrF = a.botF + (size_t)wr_slot(a, s) * a.NP;
   int obH = 0, obF = 0;
   uint32_t* tdst = a.trace + (((size_t)(s - a.trace_s0) * a.W + (Tb >> 4)) * 64 + lane) * K;
-#pragma unroll kUnroll
+#pragma unroll 1
   for (int sub = 0; sub < 4; ++sub) {
     uint32_t tacc[K], sbk[K], skp[K];
 #pragma unroll
@@ -359,15 +366,9 @@ __device__ __forceinline__ void run_block(Lane<KIND, K>& st, const FillArgs& a, 
     // sank all packing ops of the sub-block into the branch instead of spreading them over the steps.
     if (!(FLAGS & FLAG_NOTRACE)) store_trace<K>(tdst, tacc);
     tdst += 64 * K;
-    hook(sub);
   }
-  if (PERSIST) {
-    st_coherent(wrH + Tb + 1 + lane, obH);
-    if (KIND != KIND_LCS) st_coherent(wrF + Tb + 1 + lane, obF);
-  } else {
-    wrH[Tb + 1 + lane] = obH;
-    if (KIND != KIND_LCS) wrF[Tb + 1 + lane] = obF;
-  }
+  wrH[Tb + 1 + lane] = obH;
+  if (KIND != KIND_LCS) wrF[Tb + 1 + lane] = obF;
 }
 
 // lane state at the first column of a strip, from the left border (values of matrix column 0 of
@@ -500,9 +501,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_tile(const FillArgs 
     int ibH, ibF, yb;
     load_block_inputs<KIND, K, FLAGS>(a, s, Tb, lane, ibH, ibF, yb);
     if (interior)
-      run_block<KIND, K, false, FLAGS>(st, a, s, Tb, lane, ldsLane, xr, dprow, ibH, ibF, yb, NoHook());
+      run_block<KIND, K, false, FLAGS>(st, a, s, Tb, lane, ldsLane, xr, dprow, ibH, ibF, yb);
     else
-      run_block<KIND, K, true, FLAGS>(st, a, s, Tb, lane, ldsLane, xr, dprow, ibH, ibF, yb, NoHook());
+      run_block<KIND, K, true, FLAGS>(st, a, s, Tb, lane, ldsLane, xr, dprow, ibH, ibF, yb);
   }
 
   if (q == qmax) {
@@ -530,17 +531,110 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_tile(const FillArgs 
 
 // ---- persistent strip pipeline ---------------------------------------------------------------
 // One launch for the whole fill.  A wave draws strips from a ticket counter in ascending order and
-// sweeps each one block by block (64 steps); before block b of strip s it waits until strip s-1
-// has published b+2 finished blocks (it reads bottom-row entries that strip s-1 writes at the end
-// of its block b+1), so consecutive strips run 128 steps apart and nothing is saved or restored
-// between tiles.  Deadlock-free for any grid size: tickets are only handed to running waves, in
-// order, so the lowest unfinished strip is always held by a resident wave whose predecessor is
-// complete.  Every spin is bounded (spin_limit); a wave that gives up raises *err and every
-// waiting wave leaves when it sees it.
+// sweeps each one in sub-blocks of 16 steps.  Lane 0 of strip s consumes, at its step t, the bottom-row
+// record of column t of strip s-1, which lane 63 of that strip produces at ITS step t + 63 and hands
+// down (ho_store, lanes 48..63 of the rotating out-buffers) at the end of the 16-step sub-block that
+// contains that step: consecutive strips run 80 steps + one store-to-load latency apart (they ran two
+// 64-step blocks + a flag round trip apart when the hand-off was per block behind a progress word), and
+// nothing is saved or restored between tiles.  The records of the NEXT sub-block are requested
+// right after those of the current one have been installed, so the load has 16 steps to land; if the
+// producer has not written them yet (their generation bit says so), the wave re-reads them (bounded).
+// Deadlock-free for any grid size: tickets are only handed to running waves, in order, so the lowest
+// unfinished strip is always held by a resident wave whose predecessor is complete.  Every spin is
+// bounded (spin_limit); a wave that gives up raises *err and every waiting wave leaves when it sees it.
+
+// How many sub-blocks ahead the records are requested.  An agent-scope load takes about 0.85 us on an idle MI355X
+// (measured: one strip alone, tools/perf_step.py); a 16-step sub-block of NW / SW lasts 0.73 us (K = 1) .. 2.6 us
+// (K = 8) and one sub-block ahead is enough (two cost K = 8 its registers: 164 -> 179 ns per step); the LCS cell is
+// cheaper (0.56 us per sub-block at K = 1) and asks two sub-blocks ahead.  Must divide 4 (sub-blocks per block).
+template <int KIND, int K>
+struct HandoffDepth {
+  static constexpr int D = KIND == KIND_LCS ? 2 : 1;
+};
+
+// Take the hand-off records of the sub-block that starts at step Ts (lanes 0..15: columns Ts .. Ts+15), requested
+// D sub-blocks earlier into `cur`, install them in the in-buffers and request those D sub-blocks further on into
+// the same registers.  A record is valid when it carries the generation of the strip above; columns >= n are never
+// produced (and never used: their cells are inactive).  Returns false when the bounded wait expired.
+#ifdef SA_DEBUG_HANDOFF
+__device__ int g_dbg_episodes, g_dbg_rereads;  // per wave would be better; one strip per wave at a time is close enough
+#endif
+template <int KIND, int K>
+__device__ __forceinline__ bool handoff_acquire(const FillArgs& a, int2& cur, const int2* rd, const int Ts, const int lane,
+                                                const int gen_r, int& ibH, int& ibF, int* dbgc = nullptr) {
+  // no short-circuit: one straight-line test on all lanes, so that the wait for the load sits on every path
+  const int need = (lane < 16) & (Ts + lane < a.n);
+  if (__builtin_expect(__ballot(need & ho_stale(cur.x, gen_r)) != 0ull, 0)) {
+    // every way out of this loop has waited for its load (the test comes first), so that where the paths join the
+    // compiler knows that nothing loaded is pending and leaves the fast path's counted waits alone
+    int spins = 0;
+    while (true) {
+      __builtin_amdgcn_s_sleep(1);
+      cur = ho_load(rd + Ts);
+      if (__ballot(need & ho_stale(cur.x, gen_r)) == 0ull) break;
+      if (++spins > a.spin_limit || ((spins & 255) == 0 && ld_coherent(a.err) != 0)) return false;
+    }
+#ifdef SA_DEBUG_HANDOFF
+    if (dbgc) dbgc[0] += 1, dbgc[1] += spins;
+#endif
+  }
+  ibH = ho_value(cur.x);
+  ibF = cur.y;
+  cur = ho_load(rd + Ts + 16 * HandoffDepth<KIND, K>::D);  // in flight during the next D sub-blocks
+  return true;
+}
+
+// 64 steps (four sub-blocks expanded in line) of one strip.  On entry ibH / ibF hold the records of the block's
+// first sub-block (handoff_acquire), on return those of the next block's first.  The records of the following
+// sub-block are taken right after a sub-block's 16 steps and BEFORE its own stores are issued: whatever the wait
+// for the request has to wait for (vmcnt counts loads and stores together, in order, and the compiler waits for
+// everything where the re-read path joins) was issued at least 16 steps earlier.
+// ny: the next block's 64 target symbols, requested during sub-block 2.  Returns false when a bounded wait expired.
+template <int KIND, int K, bool BND, int FLAGS>
+__device__ __forceinline__ bool run_block_p(Lane<KIND, K>& st, const FillArgs& a, const int s, const int Tb, const int lane,
+                                            const char* ldsLane, const uint32_t (&xr)[K], int* dprow, int yb, int& ny,
+                                            int2 (&pend)[HandoffDepth<KIND, K>::D], int& ibH, int& ibF, int& obH, int& obF,
+                                            const int2* rd, int2* wr, const int gen_r, const int gen_w, int* dbgc = nullptr) {
+  constexpr int D = HandoffDepth<KIND, K>::D;
+  uint32_t* tdst = a.trace + (((size_t)(s - a.trace_s0) * a.W + (Tb >> 4)) * 64 + lane) * K;
+#pragma unroll
+  for (int sub = 0; sub < 4; ++sub) {
+    const int Ts = Tb + 16 * sub;
+    uint32_t tacc[K], sbk[K], skp[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) tacc[k] = 0, sbk[k] = 0, skp[k] = 0;
+    const int cbase = Ts - lane;
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      lane_step<KIND, K, BND, FLAGS>(st, ibH, ibF, yb, obH, obF, tacc, u, ldsLane, xr, a, cbase + u, dprow, sbk, skp);
+    if (KIND == KIND_SW) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const int v = (int)(sbk[k] >> 4) << 2;  // the 4 * score of the sub-block's best cell in this row
+        const bool better = v > st.best[k];     // strict: earlier sub-blocks hold the smaller columns
+        st.best[k] = better ? v : st.best[k];
+        st.bestc[k] = better ? cbase + 15 - (int)(sbk[k] & 15u) : st.bestc[k];
+      }
+    }
+    if (!handoff_acquire<KIND, K>(a, pend[(sub + 1) % D], rd, Ts + 16, lane, gen_r, ibH, ibF, dbgc)) return false;
+    if (sub == 2) ny = a.yenc[Tb + 64 + lane];
+    if (!(FLAGS & FLAG_NOTRACE)) store_trace<K>(tdst, tacc);
+    tdst += 64 * K;
+    // The out-buffers are rotated once per step, through the whole strip: lane L holds the record of step
+    // Ts + L - 48, i.e. of the bottom-row column Ts + L - 111 (index p = Ts + L - 47).  Lanes 48..63 hold the 16
+    // new ones; interior blocks let every lane store (the older records are rewritten with the values they already
+    // have) so that the store sits on every path and the compiler can count it in its waits; the first block
+    // of a strip (always a BND instance) must not: its lower lanes hold steps before the strip began.
+    if (!BND || lane >= 48) ho_store(wr + Ts, obH, obF, gen_w);
+  }
+  return true;
+}
+
 template <int KIND, int K, int FLAGS>
 __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const FillArgs a) {
   using G = Geo<KIND, K>;
   constexpr int PF = FLAGS | FLAG_PERSIST;
+  constexpr bool YSCALE = KIND != KIND_LCS || (FLAGS & FLAG_LPROF);
   extern __shared__ uint32_t lds_all[];
   const int lane = threadIdx.x & 63;
   uint32_t* lds = lds_all + (threadIdx.x >> 6) * (a.alpha * 64 * G::PW);
@@ -592,88 +686,41 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
 #pragma unroll
       for (int k = 0; k < K; ++k) st.Hg[k] = add_gap<(FLAGS & FLAG_FRAC) != 0>(st.H[k], a.go, a.fo) + 1;
     }
-    // Block loop.  Everything with memory latency is taken off the critical path:
-    //  * the progress word of strip s-1 is polled after sub-block 1 of the CURRENT block and looked
-    //    at after sub-block 2; if it already covers the next block, that block's inputs are loaded
-    //    right there (behind the poll, as the hand-off protocol requires) and arrive while
-    //    sub-block 3 computes; only a strip that has caught up with its predecessor takes the
-    //    blocking path at the top;
-    //  * the completion of block b-1 is published after sub-block 0 of block b, behind a counted
-    //    vmcnt that leaves only the trace stores just issued in flight, instead of draining the
-    //    store queue at every block end.
-    int seen = 0;            // blocks strip s-1 is known to have published
-    bool have_next = false;  // inputs of the next block already in nH/nF/ny
-    int nH = 0, nF = 0, ny = 0;
-    int vzero;  // 0 in a VGPR the compiler cannot see through
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));
-    int* const my_prog = a.prog + s;
-    const bool has_up = s > a.s_first;  // the first strip of the launch finds its row above complete
-    const int* const up_prog = a.prog + (has_up ? s - 1 : s);
+    // slot and generation of the records this strip reads / writes (see ho_store); matrix row 0 is "strip -1"
+    const int gen_r = ho_gen((s / a.ring) % 3), gen_w = ho_gen(((s + 1) / a.ring) % 3);
+    const int2* rd = a.bot2 + (size_t)(s % a.ring) * a.NP + 64 + lane;          // lanes 0..15 of sub-block Ts: column Ts + lane
+    int2* wr = a.bot2 + (size_t)((s + 1) % a.ring) * a.NP + 1 + (lane - 48);    // lanes 48..63 of sub-block Ts: step Ts + lane - 48
+    int2 pend[HandoffDepth<KIND, K>::D];
+#pragma unroll
+    for (int j = 0; j < HandoffDepth<KIND, K>::D; ++j) pend[j] = ho_load(rd + 16 * j);
+    int ny = a.yenc[lane];
+    int ibH = 0, ibF = 0, obH = 0, obF = 0;
+    int* dbgc = nullptr;
+#ifdef SA_DEBUG_HANDOFF
+    int dbg_counts[2] = {0, 0};
+    dbgc = dbg_counts;
+#endif
+    dead = !handoff_acquire<KIND, K>(a, pend[0], rd, 0, lane, gen_r, ibH, ibF);
+#ifdef SA_DEBUG_HANDOFF
+    const long long dbg_t0 = wall_clock64();
+#endif
 #pragma unroll 1
-    for (int b = 0; b < NB; ++b) {
+    for (int b = 0; b < NB && !dead; ++b) {
       const int Tb = 64 * b;
-      int ibH, ibF, yb;
-      if (have_next) {
-        ibH = nH;
-        ibF = nF;
-        yb = (KIND != KIND_LCS || (FLAGS & FLAG_LPROF)) ? ny * G::ROWB : ny;
-      } else {
-        if (has_up) {
-          const int need = min(b + 2, NB);
-          int spins = 0;
-          while (seen < need) {
-            seen = ld_coherent(up_prog);
-            if (seen >= need) break;
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > a.spin_limit || ((spins & 255) == 0 && ld_coherent(a.err) != 0)) {
-              dead = true;
-              break;
-            }
-          }
-          if (dead) break;
-          asm volatile("" ::: "memory");  // data loads stay behind the poll
-        }
-        load_block_inputs<KIND, K, PF>(a, s, Tb, lane, ibH, ibF, yb);
-      }
-      have_next = false;
-      int pv = 0;
-      auto hook = [&](int sub) {
-        if (sub == 0) {
-          if (b > 0) {
-            // blocks 0..b-1 are complete once everything older than this sub-block's code
-            // stores has retired (vmcnt counts loads and stores together, in issue order)
-            if (FLAGS & FLAG_NOTRACE)  // score-only / checkpoint pass: no code stores were issued in between
-              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (K == 8)
-              asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else
-              asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            if (lane == 0) st_coherent(my_prog, b);
-          }
-        } else if (sub == 1) {
-          // Unconditional, and a per-lane load: a poll that is issued on some paths only, or whose
-          // result has to sit in an SGPR, makes the compiler wait for it (and for everything
-          // issued before it) much earlier than it is needed.
-          pv = ld_coherent(up_prog + vzero);
-        } else if (sub == 2) {
-          seen = max(seen, __builtin_amdgcn_readfirstlane(pv));
-          if (b + 1 < NB && (!has_up || seen >= min(b + 3, NB))) {
-            asm volatile("" ::: "memory");
-            load_block_inputs<KIND, K, PF, true>(a, s, Tb + 64, lane, nH, nF, ny);
-            have_next = true;
-          }
-        }
-      };
+      const int yb = YSCALE ? ny * G::ROWB : ny;
       const bool interior = (Tb >= 64) && (Tb + 63 < a.n);
-      if (interior)
-        run_block<KIND, K, false, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow, ibH, ibF, yb, hook);
-      else
-        run_block<KIND, K, true, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow, ibH, ibF, yb, hook);
+      const bool ok = interior ? run_block_p<KIND, K, false, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow, yb, ny, pend, ibH, ibF, obH, obF, rd, wr, gen_r, gen_w, dbgc)
+                               : run_block_p<KIND, K, true, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow, yb, ny, pend, ibH, ibF, obH, obF, rd, wr, gen_r, gen_w, dbgc);
+      dead = !ok;
     }
-    if (!dead) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last block's stores have completed
-      if (lane == 0) st_coherent(my_prog, NB);
+#ifdef SA_DEBUG_HANDOFF
+    if (a.dbg && lane == 0) {
+      a.dbg[4 * s + 0] = dbg_t0;
+      a.dbg[4 * s + 1] = wall_clock64();
+      a.dbg[4 * s + 2] = dbg_counts[0];
+      a.dbg[4 * s + 3] = dbg_counts[1];
     }
+#endif
     if (dead) {
       if (lane == 0) st_coherent(a.err, 1);
       break;
@@ -683,6 +730,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_fetch_add(a.chunk_done + s / a.strips_per_chunk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+  }
+}
+
+// host-initialised records of matrix row 0 (slot 0, generation 0): H[0][c+1] at index c + 64
+__global__ void init_row0_records(int2* __restrict__ dst, const int* __restrict__ h4, int n, int hconst, int f) {
+  for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
+    const int h = h4 ? h4[c] : hconst;
+    dst[64 + c] = make_int2(h & 0x3fffffff, f);
   }
 }
 

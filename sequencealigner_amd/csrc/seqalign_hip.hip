@@ -158,6 +158,8 @@ struct Tuning {
   int K, C;
 };
 
+constexpr double kHandoffLatencyUs = 2.9;  // record store (sc1) -> visible to the other CU -> its poll returns, MI355X
+
 // Pick rows-per-lane K and tile length C by a small cost model: a wave issues one VALU
 // instruction per 4 cycles and one wave saturates its SIMD (measured, profiles/), so the time
 // is max(critical path over launches, total work / 1024 SIMDs).
@@ -190,12 +192,17 @@ Tuning choose_tuning(const sa_ctx* ctx, int kind, int64_t m, int64_t n, int64_t 
   return t;
 }
 
+// Steps by which a strip trails the strip above it in the persistent pipeline: the lane skew of a strip (64), the
+// hand-off granularity (16), the distance at which the records are requested (16) and the store-to-load latency of an
+// agent-scope hand-off (measured start-to-start lags, tools/perf_handoff.py: 9.1 us at 62 ns per step, 19.3 us at 164).
+double strip_lag(double step_cycles) { return 96.0 + kHandoffLatencyUs * 1e-6 * 2.4e9 / step_cycles; }
+
 // Steps until the last of S strips of n columns is done when `waves` resident waves draw strips in
-// order: strip s starts when the strip above is 128 steps ahead AND a wave is free, i.e.
-// start(s) = max(128 s, start(s - waves) + n).
-double pipeline_steps(double S, double waves, double n) {
+// order: strip s starts when the strip above is `lag` steps ahead AND a wave is free, i.e.
+// start(s) = max(lag s, start(s - waves) + n).
+double pipeline_steps(double S, double waves, double n, double lag) {
   double start = 0;
-  for (double j = 0; j * waves <= S - 1; j += 1) start = std::max(start, 128.0 * (S - 1 - j * waves) + j * n);
+  for (double j = 0; j * waves <= S - 1; j += 1) start = std::max(start, lag * (S - 1 - j * waves) + j * n);
   return start + n;
 }
 
@@ -211,7 +218,7 @@ int choose_persist_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n, bool lpr
   for (int K : {1, 2, 4, 8}) {
     const double step = (cell * K + 18.0) * 4.0;
     const double S = std::ceil((double)m / (64.0 * K));
-    const double est = pipeline_steps(S, waves, (double)n + 63.0) * step;
+    const double est = pipeline_steps(S, waves, (double)n + 63.0, strip_lag(step)) * step;
     if (est < best) {
       best = est;
       bestK = K;
@@ -224,7 +231,7 @@ int choose_persist_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n, bool lpr
 // model of the LAST stripe's finishing time and so picks the same K: its first strip can start
 // once each stripe to its left has emitted its first border chunk (T_first each), then it works
 // through its own strips, ceil(S / resident waves) rounds of one sweep each, plus the ramp of the
-// strip chain (consecutive strips run 128 steps apart).  A large K is the cheapest per cell but the
+// strip chain (consecutive strips run strip_lag() steps apart).  A large K is the cheapest per cell but the
 // slowest per step, so the more GPUs share the columns, the smaller K gets.  Step costs measured
 // on MI355X (tools/perf_stripe_model.py): (10 K + 18) issue slots of 4 cycles for NW.
 // R > 0: K must divide the border chunk into whole strips.
@@ -240,8 +247,8 @@ int choose_stripe_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n, int64_t n
     const double step = (cell * K + step0) * 4.0;
     const double S = std::ceil((double)m / (64.0 * K));
     const double hops = n > 0 ? std::max(0.0, std::round((double)n_total / (double)n) - 1.0) : 0.0;
-    const double first = ((double)n + (R > 0 ? (double)R / (64.0 * K) : 1.0) * 128.0) * step;
-    const double est = hops * first + pipeline_steps(S, waves, (double)n + 63.0) * step;
+    const double first = ((double)n + (R > 0 ? (double)R / (64.0 * K) : 1.0) * strip_lag(step)) * step;
+    const double est = hops * first + pipeline_steps(S, waves, (double)n + 63.0, strip_lag(step)) * step;
     if (est < best) {
       best = est;
       bestK = K;
@@ -374,7 +381,10 @@ struct StripeDesc {  // internal mirror of sa_stripe_desc; all-null = the whole 
 };
 
 int check_scoring(sa_ctx* ctx, int kind, const sa_scoring* sc, int64_t m, int64_t n_total) {
-  if (kind == KIND_LCS) return SA_OK;
+  if (kind == KIND_LCS) {  // registers hold 4 L + 1, hand-off records 30 bits of it
+    if (std::min(m, n_total) >= (1 << 27)) return fail(ctx, SA_ERR_ARG, "LCS of sequences beyond 2^27 residues would overflow the 4x-scaled arithmetic");
+    return SA_OK;
+  }
   if (!sc || !sc->sub || !sc->idx256 || sc->alpha < 1 || sc->alpha > 32) return fail(ctx, SA_ERR_ARG, "bad scoring");
   if (!(std::fabs(sc->gap_open) <= 1e6) || !(std::fabs(sc->gap_extend) <= 1e6)) return fail(ctx, SA_ERR_ARG, "gap penalty out of range");
   int smax = 0;
@@ -483,7 +493,10 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   if (ckpt && !persist)
     return fail(ctx, SA_ERR_NOMEM, "%.1f GB of traceback codes exceed the budget and checkpointed recomputation needs the persistent "
                 "schedule (integral gaps, no matrix dump)", (double)S * strip_trace_bytes / 1e9);
-  const int ring = ckpt ? S + 1 : 2;
+  // slots of bottom rows: two for the launch-per-diagonal schedule; the persistent pipeline takes one per strip when
+  // it keeps checkpoints or has few strips, else two more than the launch has waves (sa_kernels.h, ho_store)
+  const int grid_blocks = std::min((S + kWavesPerBlock - 1) / kWavesPerBlock, ctx->n_cu * std::max(1, ctx->wps));
+  const int ring = !persist ? 2 : (ckpt ? S + 1 : std::min(S + 1, grid_blocks * kWavesPerBlock + 2));
   int band = S;
   if (ckpt) {
     const size_t ck_bytes = (size_t)2 * ring * NP * 4;
@@ -558,27 +571,43 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   }
   int* botH = (int*)ctx->bot.p;
   int* botF = botH + (size_t)ring * NP;
+  int2* bot2 = (int2*)ctx->bot.p;  // the persistent pipeline's view of the same memory: [ring][NP] records {H | generation, F}
   // strip 0 reads the last slot: row 0 of the matrix, H[0][j] at p = j + 63.  Every other slot is
   // written by its strip before the strip below reads it.
   int* row0H = botH + (size_t)(ring - 1) * NP;
   int* row0F = botF + (size_t)(ring - 1) * NP;
-  if (kind == KIND_LCS) {  // LCS registers hold 4 * L + 1 (sa_kernels.h): row 0 of the matrix is all ones
-    if (ring == 2)
-      HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)botH, 1, (size_t)2 * NP, st));
-    else
-      HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)row0H, 1, (size_t)NP, st));
-  } else if (ring == 2) {
-    HIPCK(ctx, hipMemsetAsync(botH, 0, (size_t)2 * NP * 4, st));
-    HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)botF, kind == KIND_NW ? kNeg : 0, (size_t)2 * NP, st));
-  } else {
-    HIPCK(ctx, hipMemsetAsync(row0H, 0, (size_t)NP * 4, st));
-    HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)row0F, kind == KIND_NW ? kNeg : 0, (size_t)NP, st));
-  }
   std::vector<int> rowb4;
   if (kind == KIND_NW) {
     rowb4.resize((size_t)n);
     for (int j = 0; j < n; ++j) rowb4[j] = 4 * rowb[j + 1];
-    HIPCK(ctx, hipMemcpyAsync(row0H + 64, rowb4.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+  }
+  if (persist) {
+    // Every record starts with generation 3 = "not yet written" (strips write generations 0..2); matrix row 0 goes
+    // into slot 0 with generation 0, as "strip -1".
+    HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)bot2, (int)0xC0000000u, (size_t)2 * ring * NP, st));
+    const int* d_h4 = nullptr;
+    if (kind == KIND_NW) {
+      if ((rc = ensure(ctx, ctx->colb, (size_t)n * 4))) return rc;
+      HIPCK(ctx, hipMemcpyAsync(ctx->colb.p, rowb4.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
+      d_h4 = (const int*)ctx->colb.p;
+    }
+    // LCS registers hold 4 * L + 1 (sa_kernels.h): row 0 is all ones; SW: zeros; F[0][j] = -inf (NW) / 0
+    hipLaunchKernelGGL(init_row0_records, dim3(std::min((n + 255) / 256, 2048)), dim3(256), 0, st, bot2, d_h4, n,
+                       kind == KIND_LCS ? 1 : 0, kind == KIND_NW ? kNeg : 0);
+  } else {
+    if (kind == KIND_LCS) {
+      if (ring == 2)
+        HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)botH, 1, (size_t)2 * NP, st));
+      else
+        HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)row0H, 1, (size_t)NP, st));
+    } else if (ring == 2) {
+      HIPCK(ctx, hipMemsetAsync(botH, 0, (size_t)2 * NP * 4, st));
+      HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)botF, kind == KIND_NW ? kNeg : 0, (size_t)2 * NP, st));
+    } else {
+      HIPCK(ctx, hipMemsetAsync(row0H, 0, (size_t)NP * 4, st));
+      HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)row0F, kind == KIND_NW ? kNeg : 0, (size_t)NP, st));
+    }
+    if (kind == KIND_NW) HIPCK(ctx, hipMemcpyAsync(row0H + 64, rowb4.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
   }
   HIPCK(ctx, hipMemsetAsync(ctx->small.p, 0, 256, st));
   int* d_score = (int*)ctx->small.p;                                           // [0]   NW/LCS score / SW best
@@ -617,6 +646,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   a.dp = dump ? (int*)ctx->dpbuf.p : nullptr;
   a.botH = botH;
   a.botF = botF;
+  a.bot2 = bot2;
   a.state = (int*)ctx->state.p;
   a.trace = (ckpt || no_tb) ? nullptr : (uint32_t*)ctx->trace.p;  // checkpoint pass / score only: no codes
   a.trace_s0 = 0;
@@ -635,8 +665,20 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   int slo = 0, shi = -1, launches = 0;
   if (persist) {
     HIPCK(ctx, hipMemsetAsync(ctx->pbuf.p, 0, pbuf_ints * 4, st));
-    a.prog = (int*)ctx->pbuf.p + 64;
     a.ticket = (int*)ctx->pbuf.p;
+#ifdef SA_DEBUG_HANDOFF
+    {
+      static void* dbgbuf = nullptr;
+      static size_t dbgcap = 0;
+      if (dbgcap < (size_t)S * 32) {
+        if (dbgbuf) (void)hipFree(dbgbuf);
+        HIPCK(ctx, hipMalloc(&dbgbuf, (size_t)S * 32));
+        dbgcap = (size_t)S * 32;
+      }
+      HIPCK(ctx, hipMemsetAsync(dbgbuf, 0, (size_t)S * 32, st));
+      a.dbg = (long long*)dbgbuf;
+    }
+#endif
     a.err = (int*)ctx->small.p + 40;  // byte 160 of the small block, read back with the score
     a.spin_limit = 1 << 22;
     if (striped && ev_in) a.rows_in = (int*)ctx->pbuf.p + 32;
@@ -653,7 +695,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   }
   HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
   if (persist) {
-    const dim3 grid(std::min((S + kWavesPerBlock - 1) / kWavesPerBlock, ctx->n_cu * std::max(1, ctx->wps)));
+    const dim3 grid(grid_blocks);
     if (kind == KIND_NW)
       launch_persistent<KIND_NW>(K, grid, lds, st, a, ckpt || no_tb);
     else if (kind == KIND_SW)
@@ -707,6 +749,20 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
     }
   }
   HIPCK(ctx, hipGetLastError());
+#ifdef SA_DEBUG_HANDOFF
+  if (persist && a.dbg) {
+    std::vector<long long> h((size_t)4 * S);
+    HIPCK(ctx, hipStreamSynchronize(st));
+    HIPCK(ctx, hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
+    double lag = 0, dur = 0, ep = 0, rr = 0;
+    const int lim = std::min(S, grid_blocks * kWavesPerBlock);
+    for (int q = 1; q < lim; ++q) lag += (double)(h[4 * q] - h[4 * (q - 1)]);
+    for (int q = 0; q < S; ++q) dur += (double)(h[4 * q + 1] - h[4 * q]), ep += (double)h[4 * q + 2], rr += (double)h[4 * q + 3];
+    fprintf(stderr, "[handoff] K=%d S=%d n=%d: mean start-to-start lag of the first %d strips %.2f us, mean strip duration %.1f us (%.1f ns/step), "
+            "re-read episodes per strip %.1f, re-reads per strip %.1f; span first start -> last end %.1f us; strip 0 alone: %.1f ns/step\n", K, S, n, lim, lag / std::max(1, lim - 1) / 100.0,
+            dur / S / 100.0, dur / S * 10.0 / (n + 63), ep / S, rr / S, (double)(h[4 * (S - 1) + 1] - h[0]) / 100.0, (double)(h[1] - h[0]) * 10.0 / (n + 63));
+  }
+#endif
   out->n_launches = launches;
   if (kind == KIND_SW) {
     const int rb = std::min((m + 255) / 256, 1024);

@@ -24,7 +24,25 @@ import os
 
 import numpy as np
 
-from .engine import SA_EV_NEED_LEFT, AlignResult
+from .engine import MODES, SA_ERR_INVALID_CODE, SA_EV_NEED_LEFT, AlignResult, SeqAlignError, load_library
+
+
+def first_invalid_pair(x: np.ndarray, y: np.ndarray, mode: str):
+    """The residue pair the reference's lazy check would throw on first, scanning the cells in its row-major
+    fill order (main.cpp:640 inside :622, :738) -- the host-side rule of the library (seqalign_hip.hip,
+    first_invalid_pair), evaluated here on the WHOLE x and y: every rank holds both, so every rank reaches the
+    same verdict before any border transfer is posted.  None when every cell is valid."""
+    sc = load_library().sa_builtin_scoring(MODES[mode]).contents
+    idx = np.ctypeslib.as_array((np.ctypeslib.ctypes.c_uint8 * 256).from_address(sc.idx256))
+    if len(x) == 0 or len(y) == 0:
+        return None
+    bad_y = np.flatnonzero(idx[y] == 255)
+    bad_x = np.flatnonzero(idx[x] == 255)
+    if len(bad_y):  # row 1 already meets it: at column 1 if x[0] itself is invalid, else at the first bad column
+        return (chr(x[0]), chr(y[0])) if len(bad_x) and bad_x[0] == 0 else (chr(x[0]), chr(y[bad_y[0]]))
+    if len(bad_x):
+        return chr(x[bad_x[0]]), chr(y[0])
+    return None
 
 
 class GpuStripeEngine:
@@ -136,6 +154,12 @@ class StripedAligner:
         m, n = len(x), len(y)
         if G == 1 or m == 0 or n < self.min_stripe_cols * G:
             return self._on_rank0(kind, x, y, mode, gap_open, gap_extend)
+        # Go / no-go BEFORE any transfer is posted, identical on every rank: a stripe fill that refused its input on
+        # one rank only (the bad residue sits in that rank's columns) would leave its neighbours' transfers unmatched.
+        if kind != "lcs":
+            bad = first_invalid_pair(x, y, mode)
+            if bad is not None:
+                raise SeqAlignError(SA_ERR_INVALID_CODE, f"invalid residue pair {bad[0]},{bad[1]}", bad)
 
         with (E.stream_context() if hasattr(E, "stream_context") else contextlib.nullcontext()):
             return self._align_striped(kind, x, y, m, n, mode, gap_open, gap_extend)
@@ -154,6 +178,9 @@ class StripedAligner:
         kw_in = {"group": self._link(g)} if self.link_groups[0] is not None else {}
         kw_out = {"group": self._link(g + 1)} if self.link_groups[0] is not None else {}
 
+        n_chunks = (m + R - 1) // R
+        posted = {True: 0, False: 0}  # chunks whose receive / send has been posted (both in ascending order)
+
         def on_event(event, k):
             lo, hi = k * R + 1, min(m, (k + 1) * R) + 1
             incoming = event == SA_EV_NEED_LEFT
@@ -162,6 +189,7 @@ class StripedAligner:
                     dist.recv(left[lo:hi], src=g - 1, **kw_in)
                 else:
                     sends.append(dist.isend(right[lo:hi], dst=g + 1, **kw_out))
+            posted[incoming] = k + 1
 
         extra = {}
         if overlapped:
@@ -174,8 +202,17 @@ class StripedAligner:
             res = E.stripe_fill(kind, x, y[c0:c1], n, c0, first, last,
                                 None if first else left.data_ptr(), None if last else right.data_ptr(), R, on_event,
                                 mode, gap_open, gap_extend, **extra)
-        except RuntimeError as e:  # e.g. a bounded wait inside the persistent kernel expired
+        except RuntimeError as e:  # e.g. a bounded wait inside the persistent kernel expired, or no memory
             failure = e
+            # This rank may have stopped before it posted (all of) its transfers, but its neighbours post every chunk:
+            # post what is missing, so that every send meets its receive and everybody reaches the vote below.  What
+            # travels is garbage; the vote discards the whole alignment.
+            if not first:
+                for k in range(posted[True], n_chunks):
+                    on_event(SA_EV_NEED_LEFT, k)
+            if not last:
+                for k in range(posted[False], n_chunks):
+                    on_event(SA_EV_NEED_LEFT + 1, k)
         with (E.transfer_context(False) if overlapped else contextlib.nullcontext()):
             for w in sends:
                 w.wait()

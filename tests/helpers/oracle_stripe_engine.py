@@ -28,6 +28,7 @@ class OracleStripeEngine:
         L.orc_stripe_best.argtypes = [vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
         L.orc_stripe_best.restype = None
         self.handle = None
+        self.fail_next = False  # tests: refuse the next stripe_fill before posting anything (as SA_ERR_NOMEM would)
 
     def alloc_border(self, m):
         return torch.zeros((m + 1, 2), dtype=torch.int32)
@@ -45,6 +46,9 @@ class OracleStripeEngine:
                     on_event, mode="dna", gap_open=-5.0, gap_extend=-1.0):
         x = np.ascontiguousarray(x, np.uint8)
         y = np.ascontiguousarray(y_stripe, np.uint8)
+        if self.fail_next:
+            self.fail_next = False
+            raise RuntimeError("injected failure before any transfer was posted")
         err = []
 
         def _cb(_u, ev, k):

@@ -48,6 +48,35 @@ def main():
                 if not good:
                     print(f"rank {rank}: MISMATCH {kind} m={len(x)} n={len(y)} go={go}: {r.score} vs {want.score}", flush=True)
                 ok = ok and good
+    # An invalid residue in the LAST stripe's columns only: every rank must raise the reference's error (same pair)
+    # before any transfer is posted -- nobody hangs -- and the next alignment works.
+    from sequencealigner_amd.engine import SeqAlignError
+    from sequencealigner_amd.stripes import StripeError
+
+    x, y = dna_pair(600, seed=11)
+    yb = y.copy()
+    yb[len(yb) - 3] = ord("z")
+    try:
+        al.align("nw", x, yb, "dna")
+        ok = False
+        print(f"rank {rank}: no error for an invalid residue", flush=True)
+    except SeqAlignError as e:
+        good = e.code == -2 and e.bad == (chr(x[0]), "z")
+        if not good:
+            print(f"rank {rank}: wrong error {e} {e.bad}", flush=True)
+        ok = ok and good
+    # One rank's stripe fill fails before it posts anything (as an allocation failure would): its neighbours have
+    # posted every chunk; the failed rank posts the matching transfers, all ranks vote and all raise StripeError.
+    for failing in range(world):
+        al.engine.fail_next = rank == failing
+        try:
+            al.align("nw", x, y, "dna")
+            ok = False
+            print(f"rank {rank}: no StripeError when rank {failing} fails", flush=True)
+        except StripeError:
+            pass
+    r = al.align("nw", x, y, "dna")
+    ok = ok and r.score == orc.nw(x, y, "dna").score
     dist.barrier()
     dist.destroy_process_group()
     print(f"rank {rank}: {'STRIPES_OK' if ok else 'STRIPES_FAIL'}", flush=True)

@@ -145,3 +145,43 @@ def test_cli_batch_mode_equals_single_pair_runs(tmp_path):
     r = subprocess.run([str(PKG / "aligner"), "--query", str(q), "--target", str(tmp_path / "t0.fa"), "--choice", "2", "--mode",
                         "protein", "--outdir", str(tmp_path / "bad"), "--batch"], capture_output=True, text=True, timeout=60)
     assert r.returncode == 0 and r.stderr.startswith("Error: --batch needs the same number of records")
+
+
+def test_cli_batch_mode_fractional_gaps_fall_back_per_pair(tmp_path):
+    """--batch with penalties the many-pair kernels do not take (the reference accepts any double, main.cpp:41-43):
+    every method, local alignments included, goes pair by pair and the files equal the single-pair CLI's."""
+    import numpy as np
+
+    from conftest import PROT20, mutate, rand_seq
+
+    rng = np.random.default_rng(6)
+    pairs = []
+    for k, m in enumerate([50, 260, 120]):
+        x = rand_seq(rng, m, PROT20)
+        pairs.append((f"sp|Q{k:05d}|QRY{k}_TEST q GN=GQ{k}", x, f"sp|T{k:05d}|TGT{k}_TEST t GN=GT{k}", mutate(rng, x, PROT20, 0.2, 0.05, 0.05)))
+    q, t = tmp_path / "q.fa", tmp_path / "t.fa"
+    q.write_text("".join(f">{h}\n{x}\n" for h, x, _, _ in pairs))
+    t.write_text("".join(f">{h}\n{y}\n" for _, _, h, y in pairs))
+    out = tmp_path / "batch"
+    gaps = ["--gap_open", "-5.5", "--gap_extend", "-0.5"]
+    r = subprocess.run([str(PKG / "aligner"), "--query", str(q), "--target", str(t), "--choice", "4", "--mode", "protein",
+                        "--outdir", str(out), "--batch"] + gaps, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stderr == "", r.stderr
+    for k, (hq, x, ht, y) in enumerate(pairs):
+        sq, st = tmp_path / f"q{k}.fa", tmp_path / f"t{k}.fa"
+        sq.write_text(f">{hq}\n{x}\n")
+        st.write_text(f">{ht}\n{y}\n")
+        single = tmp_path / f"single{k}"
+        r1 = subprocess.run([str(PKG / "aligner"), "--query", str(sq), "--target", str(st), "--choice", "4", "--mode", "protein",
+                             "--outdir", str(single)] + gaps, capture_output=True, text=True, timeout=120)
+        assert r1.returncode == 0 and r1.stderr == ""
+        names = sorted(p.name for p in single.iterdir())
+        assert len(names) == 9 and names == sorted(p.name for p in (out / f"pair_{k + 1}").iterdir())
+        for name in names:
+            a, b = (single / name).read_text(), (out / f"pair_{k + 1}" / name).read_text()
+            if name.endswith(".json"):
+                ja, jb = json.loads(a), json.loads(b)
+                ja.pop("time_ms"), jb.pop("time_ms")
+                assert ja == jb, (k, name)
+            else:
+                assert a == b, (k, name)
