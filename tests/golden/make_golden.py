@@ -187,8 +187,38 @@ def big():
     return out
 
 
+def dumps():
+    """--txt / --binary matrix dumps (main.cpp:422-528; call sites :825-831, :1364-1368, :1680-1691) exactly as the
+    reference writes them: every file it produced, bytes in base64 (small cases only).  Three flag settings per pair:
+    --txt, --binary, and both (the reference lets --binary win for the S / L matrices, main.cpp:825-829)."""
+    import base64
+
+    rng = np.random.default_rng(424242)
+    xp = rand_seq(rng, 37, PROT20)
+    cases = [("d0", "ACGTTGCAAGCT", "ACGTGCATAGT", "dna"), ("d1", rand_seq(rng, 70, DNA), rand_seq(rng, 23, DNA), "dna"),
+             ("d2", "ACGTRYSWKMBDHVN", "NACGTAAC", "dna"), ("p0", xp, mutate(rng, xp, PROT20, 0.2, 0.1, 0.1), "protein"),
+             ("p1", "W", "ARNDW", "protein"), ("e0", "", "ACGT", "dna"), ("e1", "ACG", "", "dna")]
+    out = []
+    for cid, x, y, mode in cases:
+        tmp = tempfile.mkdtemp(prefix="gold_")
+        try:
+            qa, ta = os.path.join(tmp, "q.fasta"), os.path.join(tmp, "t.fasta")
+            write_fasta(qa, "seqA dump query", x)
+            write_fasta(ta, "seqB dump target", y)
+            for flags in (["--txt"], ["--binary"], ["--txt", "--binary"]):
+                rc, so, se, files, outdir = run_reference(qa, ta, 4, mode, extra=flags)
+                shutil.rmtree(outdir, ignore_errors=True)
+                out.append({"id": cid + "_" + "".join(f.strip("-")[0] for f in flags), "x": x, "y": y, "mode": mode, "flags": flags, "rc": rc,
+                            "stderr": se.decode("latin-1"),
+                            "files": {k: base64.b64encode(v).decode() for k, v in sorted(files.items()) if not k.endswith("_stats.json")}})
+                print("dumps", out[-1]["id"], rc, sorted(files), flush=True)
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
 def main():
-    only = sys.argv[1:] or ["random", "errors", "tables", "bundled", "big"]
+    only = sys.argv[1:] or ["random", "errors", "tables", "bundled", "big", "dumps"]
     with ProcessPoolExecutor(max_workers=6) as ex:
         if "random" in only:
             res = list(ex.map(run_case, random_cases(), chunksize=4))
@@ -209,6 +239,8 @@ def main():
         (HERE / "bundled.json").write_text(json.dumps(bundled(), indent=1))
     if "big" in only:
         (HERE / "big.json").write_text(json.dumps(big(), indent=1))
+    if "dumps" in only:
+        (HERE / "dumps.json").write_text(json.dumps(dumps(), indent=0))
 
 
 if __name__ == "__main__":

@@ -61,10 +61,28 @@ def test_cli_config3_100k_equals_reference(tmp_path, case):
     check_files(out, c["files"], GLOBAL_FILES)
 
 
+def test_cli_dump_files_equal_reference(tmp_path):
+    """--txt / --binary through the GPU CLI against the files the reference itself wrote for the same inputs
+    (tests/golden/dumps.json): all seven dump files incl. lcs_traceback_pointers.{txt,bin}, the --binary-wins rule,
+    and every ordinary result file beside them."""
+    from make_golden_shared import write_fasta
+    from test_oracle_golden import _dump_cases, check_dump_files
+
+    for c in _dump_cases():
+        d = tmp_path / c["id"]
+        d.mkdir()
+        write_fasta(d / "q.fasta", "seqA dump query", c["x"])
+        write_fasta(d / "t.fasta", "seqB dump target", c["y"])
+        out = d / "o"
+        r = subprocess.run([str(PKG / "aligner"), "--query", str(d / "q.fasta"), "--target", str(d / "t.fasta"), "--choice", "4",
+                            "--mode", c["mode"], "--outdir", str(out)] + c["flags"], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0 and r.stderr == c["stderr"], (c["id"], r.stderr)
+        check_dump_files(out, c)
+
+
 def test_cli_dp_dumps_match_reference_layout(tmp_path):
-    """--txt / --binary dumps (main.cpp:422-528): compared against files built from the oracle's
-    matrices through the same writers is circular, so the format is pinned by hand here and
-    the values by the oracle."""
+    """--txt / --binary dumps once more, values against the oracle's matrices (the byte-exact comparison with files the
+    reference wrote is test_cli_dump_files_equal_reference above)."""
     import numpy as np
 
     from oracle import Oracle
