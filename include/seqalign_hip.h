@@ -185,7 +185,8 @@ void sa_free_pool(uint8_t* pool);
  * to every pair -- the shape of the seed_aligner's per-segment align_segment_globally calls
  * (main_fmindex.cpp:1049-1143, one per anchored segment).  score[k] = S[m][n]; the op list of pair k
  * (end (m, n) -> start (0, 0), border walks included) sits in the pool as for sa_sw_batch_align.
- * A pair with an empty side is the reference's border walk.  Integral, non-positive penalties. */
+ * A pair with an empty side is the reference's border walk.  Non-positive penalties (fractional ones included:
+ * truncated toward zero per operation like the reference's int + double sums). */
 int sa_nw_batch_align(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x,
                       const int64_t* off_y, const int32_t* len_y, int64_t n_pairs, const sa_scoring* sc,
                       int32_t* score, int64_t* ops_off, int32_t* n_ops, uint8_t** ops_pool,
@@ -253,7 +254,7 @@ typedef struct {
   void* user;
   /* Optional (both NULL = the launch-per-diagonal schedule above, transfers on the ctx stream):
    * hipStream_t of the caller's receive and send streams.  When given (and the configuration
-   * allows the persistent pipeline: integral gaps, chunk_rows a multiple of 512) the stripe is ONE
+   * allows the persistent pipeline: no matrix dump, chunk_rows a multiple of 512) the stripe is ONE
    * persistent launch on the ctx stream and the border crosses while it runs: the library calls
    * SA_EV_NEED_LEFT(k) for every chunk right away -- the caller enqueues the receive of chunk k on
    * stream_in, the library follows it with a one-wave kernel that tells the running fill the rows

@@ -135,10 +135,9 @@ void run_batch_mode(sa_ctx* ctx, const Options& o) {
     sah_accession(qs[k].header.c_str(), o.mode, a, sizeof a);
     sah_accession(ts[k].header.c_str(), o.mode, b, sizeof b);
   };
-  // The many-pair kernels take integral, non-positive penalties; anything else (the reference accepts any double,
-  // main.cpp:41-43) goes pair by pair through the single-pair entry points below, for every method alike.
-  const bool batch_ok = o.gap_open == std::floor(o.gap_open) && o.gap_extend == std::floor(o.gap_extend) && o.gap_open <= 0 &&
-                        o.gap_extend <= 0 && std::fabs(o.gap_open) <= 1e4 && std::fabs(o.gap_extend) <= 1e4;
+  // The many-pair kernels take non-positive penalties (fractional ones included); anything else (the reference accepts
+  // any double, main.cpp:41-43) goes pair by pair through the single-pair entry points below, for every method alike.
+  const bool batch_ok = o.gap_open <= 0 && o.gap_extend <= 0 && std::fabs(o.gap_open) <= 1e4 && std::fabs(o.gap_extend) <= 1e4;
   if ((o.choice == 2 || o.choice == 4) && batch_ok) {
     // one engine call for every pair
     std::string pool;

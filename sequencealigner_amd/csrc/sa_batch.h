@@ -40,7 +40,9 @@ struct BatchArgs {
   const int8_t* sub;      // alpha x alpha
   const uint8_t* idx256;
   int alpha;
-  int go, ge;
+  int go, ge;             // floor of the penalties (SW: a fractional penalty acts exactly like its floor, see fill_impl)
+  int fo, fe;             // NW: 4 (the register-scale unit) if the open / extend penalty has a fractional part, else 0
+  int cgo, cge;           // NW: ceil of the penalties: the border chains stay <= 0, where trunc(v + g) = v + ceil(g)
   int CB;                 // column bits of the tracking key
   int ycap;               // LDS bytes reserved for the encoded target (sized for the longest target of the launch)
   int* score;
@@ -309,8 +311,13 @@ __global__ void __launch_bounds__(64) sw_batch_kernel(const BatchArgs a) {
 // that touch the first 64 or the last 64+ steps run a masked instance (MASK) that freezes a
 // lane's registers while its column is outside the matrix; everything in between is unmasked.
 // After the sweep every lane holds H[i][n] of its rows, the score is H[m][n].
-template <int K, bool MASK>
-__device__ __forceinline__ void nw_batch_steps(int t0, int lane, int n, int go, int ge, const char* ldsLane, const uint8_t* yenc,
+// FRAC: fractional penalties, int + double truncated toward zero per operation (main.cpp:603-604, 625-634): inside
+// the matrix add_gap<true> (floor of the penalty + 1 for a negative sum, sa_kernels.h); the borders are sums of
+// non-positive terms, where the truncation is "+ ceil(penalty)", so their closed forms keep their shape with
+// cgo / cge: H[i][0] = cgo + (i-1) max(cgo, cge), H[0][j] = cgo + (j-1) cge.
+template <int K, bool MASK, bool FRAC>
+__device__ __forceinline__ void nw_batch_steps(int t0, int lane, int n, int go, int ge, int fo, int fe, int cgo, int cge,
+                                               const char* ldsLane, const uint8_t* yenc,
                                                int (&H)[K], int (&E)[K], int& passH, int& passF, int& dprev, int& ypass, int& yb,
                                                int& yv, uint32_t (&pw_io)[BatchGeo<K>::PW], uint32_t* tdst) {
   using G = BatchGeo<K>;
@@ -325,8 +332,8 @@ __device__ __forceinline__ void nw_batch_steps(int t0, int lane, int n, int go, 
     const uint32_t (&pw)[G::PW] = pwb[u & 1];
     uint32_t (&pw_next)[G::PW] = pwb[(u & 1) ^ 1];
     const int t = t0 + u;
-    // lane 0 sits under row 0 of the matrix: H[0][t+1] = go + t ge (tag-free), F[0][.] = -inf
-    int up = dpp_shr1(go + t * ge, passH);
+    // lane 0 sits under row 0 of the matrix: H[0][t+1] = cgo + t cge (tag-free), F[0][.] = -inf
+    int up = dpp_shr1(cgo + t * cge, passH);
     int uf = dpp_shr1(kNeg, passF);
     if (u == 15 && ((t0 + 16) & 63) == 0) yb = (int)yenc[t + 1 + lane] * G::ROWB;
     ypass = yv;
@@ -362,8 +369,8 @@ __device__ __forceinline__ void nw_batch_steps(int t0, int lane, int n, int go, 
     for (int k = 0; k < K; ++k) {
       const int sg = (int)(int8_t)(pw[k / 4] >> (8 * (k & 3)));  // 4 sigma + 2
       const int left = H[k];
-      int f = max(up + go, uf + ge);            // tag 0
-      int e = max(left + go + 1, E[k] + ge);    // tag 1
+      int f = max(add_gap<FRAC>(up, go, fo), add_gap<FRAC>(uf, ge, fe));            // tag 0
+      int e = max(add_gap<FRAC>(left, go, fo) + 1, add_gap<FRAC>(E[k], ge, fe));    // tag 1
       const int mv = diag + sg;                 // tag 2
       const int ht = max(max(mv, e), f);
       tacc[k] = __builtin_amdgcn_alignbit((uint32_t)ht, tacc[k], 2);
@@ -390,7 +397,7 @@ __device__ __forceinline__ void nw_batch_steps(int t0, int lane, int n, int go, 
   for (int k = 0; k < K; ++k) tdst[k] = tacc[k];
 }
 
-template <int K>
+template <int K, bool FRAC>
 __global__ void __launch_bounds__(64) nw_batch_kernel(const BatchArgs a) {
   using G = BatchGeo<K>;
   extern __shared__ uint32_t lds[];
@@ -445,16 +452,17 @@ __global__ void __launch_bounds__(64) nw_batch_kernel(const BatchArgs a) {
   __syncthreads();
 
   const char* ldsLane = reinterpret_cast<const char*>(prof) + lane * 4 * G::PW;
-  const int go = 4 * a.go, ge = 4 * a.ge, gmax = max(go, ge);
+  const int go = 4 * a.go, ge = 4 * a.ge, fo = a.fo, fe = a.fe;
+  const int cgo = 4 * a.cgo, cge = 4 * a.cge, gmax = max(cgo, cge);
   int H[K], E[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
     const int i = lane * K + k + 1;          // matrix row of this register
-    H[k] = go + (i - 1) * gmax;              // H[i][0]
+    H[k] = cgo + (i - 1) * gmax;             // H[i][0]
     E[k] = kNeg | 1;                         // E[i][0] = -inf, tag 1
   }
   const int r0 = lane * K;                   // H[r0][0]: the diagonal of the lane's first cell
-  int dprev = r0 == 0 ? 0 : go + (r0 - 1) * gmax;
+  int dprev = r0 == 0 ? 0 : cgo + (r0 - 1) * gmax;
   int passH = H[K - 1], passF = kNeg;
   int ypass = alpha * G::ROWB;
   const int nsteps = ((n + 63 + 15) / 16) * 16;
@@ -485,9 +493,9 @@ __global__ void __launch_bounds__(64) nw_batch_kernel(const BatchArgs a) {
   for (int t0 = 0; t0 < nsteps; t0 += 16) {
     // unmasked only if every lane's column is inside [0, n) for all 16 steps
     if (t0 >= 64 && t0 + 15 < n)
-      nw_batch_steps<K, false>(t0, lane, n, go, ge, ldsLane, yenc, H, E, passH, passF, dprev, ypass, yb, yv, pw, tdst);
+      nw_batch_steps<K, false, FRAC>(t0, lane, n, go, ge, fo, fe, cgo, cge, ldsLane, yenc, H, E, passH, passF, dprev, ypass, yb, yv, pw, tdst);
     else
-      nw_batch_steps<K, true>(t0, lane, n, go, ge, ldsLane, yenc, H, E, passH, passF, dprev, ypass, yb, yv, pw, tdst);
+      nw_batch_steps<K, true, FRAC>(t0, lane, n, go, ge, fo, fe, cgo, cge, ldsLane, yenc, H, E, passH, passF, dprev, ypass, yb, yv, pw, tdst);
     tdst += 64 * K;
   }
   // H[m][n]: row m-1 lives in lane (m-1)/K, register (m-1)%K

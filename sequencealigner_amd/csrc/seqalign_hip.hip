@@ -277,9 +277,27 @@ void launch_fill(int K, int fl, dim3 grid, size_t lds, hipStream_t st, const Fil
 }
 
 // notrace: the FLAG_NOTRACE instances (score-only calls, the checkpoint pass): no codes are packed or stored
+// frac: NW with a fractional gap penalty (the FLAG_FRAC instances: one more VALU op per gap add; SW and LCS never need them)
 template <int KIND>
-void launch_persistent(int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a, bool notrace = false, bool lprof = false) {
+void launch_persistent(int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a, bool notrace = false, bool lprof = false,
+                       bool frac = false) {
   const dim3 blk(64 * kWavesPerBlock);
+  if constexpr (KIND == KIND_NW) {
+    if (frac) {
+      constexpr int F = FLAG_FRAC, FN = FLAG_FRAC | FLAG_NOTRACE;
+      switch (notrace ? -K : K) {
+        case 1: hipLaunchKernelGGL((fill_persistent<KIND, 1, F>), grid, blk, lds, st, a); break;
+        case 2: hipLaunchKernelGGL((fill_persistent<KIND, 2, F>), grid, blk, lds, st, a); break;
+        case 4: hipLaunchKernelGGL((fill_persistent<KIND, 4, F>), grid, blk, lds, st, a); break;
+        case 8: hipLaunchKernelGGL((fill_persistent<KIND, 8, F>), grid, blk, lds, st, a); break;
+        case -1: hipLaunchKernelGGL((fill_persistent<KIND, 1, FN>), grid, blk, lds, st, a); break;
+        case -2: hipLaunchKernelGGL((fill_persistent<KIND, 2, FN>), grid, blk, lds, st, a); break;
+        case -4: hipLaunchKernelGGL((fill_persistent<KIND, 4, FN>), grid, blk, lds, st, a); break;
+        default: hipLaunchKernelGGL((fill_persistent<KIND, 8, FN>), grid, blk, lds, st, a); break;
+      }
+      return;
+    }
+  }
   if constexpr (KIND == KIND_LCS) {
     if (lprof) {  // profile-driven LCS (small alphabets)
       constexpr int F = FLAG_LPROF, FN = FLAG_LPROF | FLAG_NOTRACE;
@@ -420,6 +438,9 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
     ge = 4 * (int)std::floor(sc->gap_extend);
     fo = sc->gap_open != std::floor(sc->gap_open) ? 4 : 0;
     fe = sc->gap_extend != std::floor(sc->gap_extend) ? 4 : 0;
+    // SW needs no sign fix: trunc(v + g) = v + floor(g) whenever that is >= 0, and <= 0 otherwise -- and the reference
+    // floors E and F at 0 individually (main.cpp:968-970), so a fractional penalty acts exactly like its floor.
+    if (kind == KIND_SW) fo = fe = 0;
     alpha = sc->alpha;
   }
   const int fl = ((fo || fe) ? FLAG_FRAC : 0) | (dump ? FLAG_DUMP : 0);
@@ -432,7 +453,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   // persistent strip pipeline: plain integral configuration; over column stripes the borders
   // must be able to cross while the kernel runs (the caller's two transfer streams)
   const bool striped = sd && !(sd->is_first && sd->is_last);
-  const bool persist = ctx->persist && fl == 0 &&
+  const bool persist = ctx->persist && !(fl & FLAG_DUMP) &&
                        (!striped || ((!ev_in || sd->stream_in) && (!ev_out || (sd->stream_out && R % 64 == 0))));
   // LCS over a small alphabet (DNA, proteins: at most 31 distinct bytes in the pair) takes its match term from an
   // LDS profile (FLAG_LPROF); any other input keeps the byte compare
@@ -452,7 +473,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   }
   if (fl & FLAG_DUMP) {
     tun.K = 1, tun.C = 64;
-  } else if (fl & FLAG_FRAC) {
+  } else if ((fl & FLAG_FRAC) && !persist) {
     tun.K = 2;
   } else if (persist && striped) {
     tun.K = choose_stripe_K(ctx, kind, m, n, sd->n_total, ev_out ? R : 0, lprof);
@@ -697,7 +718,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   if (persist) {
     const dim3 grid(grid_blocks);
     if (kind == KIND_NW)
-      launch_persistent<KIND_NW>(K, grid, lds, st, a, ckpt || no_tb);
+      launch_persistent<KIND_NW>(K, grid, lds, st, a, ckpt || no_tb, false, (fl & FLAG_FRAC) != 0);
     else if (kind == KIND_SW)
       launch_persistent<KIND_SW>(K, grid, lds, st, a, ckpt || no_tb);
     else
@@ -829,7 +850,7 @@ int traceback_ckpt(sa_ctx* ctx, int start_i, int start_j, sa_result* out) {
     const dim3 grid(std::min((s_hi - s_lo + 1 + kWavesPerBlock - 1) / kWavesPerBlock, ctx->n_cu * std::max(1, ctx->wps)));
     HIPCK(ctx, hipEventRecord(ctx->ev[5], st));
     if (kind == KIND_NW)
-      launch_persistent<KIND_NW>(K, grid, ctx->last.lds, st, a);
+      launch_persistent<KIND_NW>(K, grid, ctx->last.lds, st, a, false, false, a.fo != 0 || a.fe != 0);
     else if (kind == KIND_SW)
       launch_persistent<KIND_SW>(K, grid, ctx->last.lds, st, a);
     else
@@ -1037,8 +1058,6 @@ int run_stripe_fill(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const 
   int rc = check_scoring(ctx, kind, sc, m, d->n_total);
   if (rc) return rc;
   if (kind != KIND_LCS) {
-    if (sc->gap_open != std::floor(sc->gap_open) || sc->gap_extend != std::floor(sc->gap_extend))
-      return fail(ctx, SA_ERR_UNSUPPORTED, "fractional gap penalties are not implemented for column stripes");
     if (first_invalid_pair(x, m, y, n, sc->idx256, &out->bad_x, &out->bad_y))
       return fail(ctx, SA_ERR_INVALID_CODE, "invalid residue pair %c,%c", out->bad_x, out->bad_y);
   }
@@ -1112,7 +1131,10 @@ void launch_batch(hipStream_t st, int count, int alpha, const BatchArgs& a, bool
 
 template <int K>
 void launch_nw_batch(hipStream_t st, int count, int alpha, const BatchArgs& a) {
-  hipLaunchKernelGGL((nw_batch_kernel<K>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha, a.ycap), st, a);
+  if (a.fo || a.fe)
+    hipLaunchKernelGGL((nw_batch_kernel<K, true>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha, a.ycap), st, a);
+  else
+    hipLaunchKernelGGL((nw_batch_kernel<K, false>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha, a.ycap), st, a);
 }
 
 void launch_nw_batch_k(int K, hipStream_t st, int count, int alpha, const BatchArgs& a) {
@@ -1227,6 +1249,19 @@ void pool_release(uint8_t* pool) {
   if (drop) (void)hipHostFree(drop);
 }
 
+// Gap penalties of the many-pair kernels.  The reference adds a double penalty to an int and truncates toward zero
+// per operation (main.cpp:603-604, 958-964).  SW floors E and F at 0 individually, so a fractional penalty acts
+// exactly like its floor (see fill_impl); NW takes the floor plus the sign fix of add_gap<true> inside the matrix and
+// the ceiling along its non-positive borders.
+void set_batch_gaps(BatchArgs& a, const sa_scoring* sc, bool nw) {
+  a.go = (int)std::floor(sc->gap_open);
+  a.ge = (int)std::floor(sc->gap_extend);
+  a.cgo = (int)std::ceil(sc->gap_open);
+  a.cge = (int)std::ceil(sc->gap_extend);
+  a.fo = (nw && sc->gap_open != std::floor(sc->gap_open)) ? 4 : 0;
+  a.fe = (nw && sc->gap_extend != std::floor(sc->gap_extend)) ? 4 : 0;
+}
+
 // Outputs of the aligning variant (sa_sw_batch_align): per pair the 'X' cell and the op list.
 struct BatchAlign {
   int kind;           // KIND_SW: local alignments; KIND_NW: global alignments (end = (m, n), start = (0, 0))
@@ -1265,8 +1300,6 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
   static const sa_scoring kNoScoring{0.0, 0.0, kNoSub, 1, kNoMap};
   if (lcs) sc = &kNoScoring;
   if (!sc || !sc->sub || !sc->idx256 || sc->alpha < 1 || sc->alpha > 31) return fail(ctx, SA_ERR_ARG, "bad scoring");
-  if (sc->gap_open != std::floor(sc->gap_open) || sc->gap_extend != std::floor(sc->gap_extend))
-    return fail(ctx, SA_ERR_UNSUPPORTED, "fractional gap penalties are not implemented on the batch path");
   if (sc->gap_open > 0 || sc->gap_extend > 0 || sc->gap_open < -1e6 || sc->gap_extend < -1e6)
     return fail(ctx, SA_ERR_ARG, "batch path needs non-positive gap penalties");
   if (int rcs = check_batch_scoring(ctx, sc)) return rcs;
@@ -1420,8 +1453,7 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
     a.sub = d_sub;
     a.idx256 = d_map;
     a.alpha = alpha;
-    a.go = (int)sc->gap_open;
-    a.ge = (int)sc->gap_extend;
+    set_batch_gaps(a, sc, al && al->kind == KIND_NW);
     a.score = d_score;
     a.end_i = d_ei;
     a.end_j = d_ej;
@@ -1605,8 +1637,6 @@ int run_batch_noalloc(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, co
     return fail(ctx, SA_ERR_ARG, "sa_sw_batch_noalloc: %lld pairs exceed SA_NOALLOC_MAX_PAIRS = %zu (split the batch or use sa_sw_batch)",
                 (long long)n_pairs, kNaMaxPairs);
   if (!sc || !sc->sub || !sc->idx256 || sc->alpha < 1 || sc->alpha > 31) return fail(ctx, SA_ERR_ARG, "bad scoring");
-  if (sc->gap_open != std::floor(sc->gap_open) || sc->gap_extend != std::floor(sc->gap_extend))
-    return fail(ctx, SA_ERR_UNSUPPORTED, "fractional gap penalties are not implemented on the batch path");
   if (sc->gap_open > 0 || sc->gap_extend > 0 || sc->gap_open < -1e6 || sc->gap_extend < -1e6)
     return fail(ctx, SA_ERR_ARG, "batch path needs non-positive gap penalties");
   if (int rcs = check_batch_scoring(ctx, sc)) return rcs;
@@ -1669,8 +1699,7 @@ int run_batch_noalloc(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, co
     a.sub = (const int8_t*)(d + kNaSubOff);
     a.idx256 = (const uint8_t*)(d + kNaMapOff);
     a.alpha = alpha;
-    a.go = (int)sc->gap_open;
-    a.ge = (int)sc->gap_extend;
+    set_batch_gaps(a, sc, false);
     a.score = d_score;
     a.end_i = d_ei;
     a.end_j = d_ej;

@@ -39,7 +39,7 @@ def main():
     ok = True
     for x, y in cases:
         for kind in ("nw", "lcs", "sw"):
-            for go, ge in ((-5.0, -1.0), (-2.0, -2.0)):
+            for go, ge in ((-5.0, -1.0), (-2.0, -2.0), (-5.5, -0.5)):
                 r = al.align(kind, x, y, "dna", go, ge)
                 want = orc.lcs(x, y) if kind == "lcs" else getattr(orc, kind)(x, y, "dna", go, ge)
                 good = r.score == want.score and (rank != 0 or np.array_equal(r.ops, want.ops))

@@ -52,7 +52,7 @@ def test_batch_config5_shape(engine, oracle):
 def test_batch_gap_settings_and_dna(engine, oracle):
     rng = np.random.default_rng(2)
     lens = [(int(rng.integers(1, 400)), int(rng.integers(1, 400))) for _ in range(60)]
-    for go, ge in [(-10.0, -1.0), (-2.0, -2.0), (0.0, 0.0), (-1.0, -3.0), (-3.0, 0.0)]:
+    for go, ge in [(-10.0, -1.0), (-2.0, -2.0), (0.0, 0.0), (-1.0, -3.0), (-3.0, 0.0), (-5.5, -0.5), (-4.25, -1.75), (-0.5, -0.5)]:
         compare(engine, oracle, *make_pool(rng, lens, related=True), go=go, ge=ge)
     compare(engine, oracle, *make_pool(rng, lens, "ACGT", related=True), mode="dna")
     compare(engine, oracle, *make_pool(rng, [(30, 30)] * 20, "A"), mode="dna")  # tie storm: first row-major max
@@ -123,7 +123,8 @@ def test_batch_align_config5_shape_and_chunks(engine, oracle):
 def test_batch_align_gaps_dna_ties_and_edges(engine, oracle):
     rng = np.random.default_rng(12)
     lens = [(int(rng.integers(1, 300)), int(rng.integers(1, 300))) for _ in range(40)]
-    for go, ge in [(-10.0, -1.0), (-2.0, -2.0), (0.0, 0.0), (-1.0, -3.0)]:
+    # fractional penalties (the reference's int + double truncation, main.cpp:958-964): for SW they act like their floors
+    for go, ge in [(-10.0, -1.0), (-2.0, -2.0), (0.0, 0.0), (-1.0, -3.0), (-5.5, -0.5), (-4.25, -1.75), (-0.5, -0.5), (-7.9, -0.1)]:
         compare_align(engine, oracle, *make_pool(rng, lens, related=True), go=go, ge=ge)
     compare_align(engine, oracle, *make_pool(rng, lens, "ACGT", related=True), mode="dna")
     compare_align(engine, oracle, *make_pool(rng, [(30, 30)] * 10 + [(200, 90)] * 3, "A"), mode="dna")  # tie storms
@@ -171,8 +172,12 @@ def test_nw_batch_align_all_row_groups(engine, oracle):
 def test_nw_batch_align_gaps_dna_ties_and_edges(engine, oracle):
     rng = np.random.default_rng(22)
     lens = [(int(rng.integers(1, 300)), int(rng.integers(1, 300))) for _ in range(40)]
-    for go, ge in [(-10.0, -1.0), (-2.0, -2.0), (0.0, 0.0), (-1.0, -3.0), (-3.0, 0.0)]:
+    # fractional penalties: the FRAC instances of the kernel (sign-dependent truncation, main.cpp:603-604, 625-634)
+    for go, ge in [(-10.0, -1.0), (-2.0, -2.0), (0.0, 0.0), (-1.0, -3.0), (-3.0, 0.0), (-5.5, -0.5), (-4.25, -1.75), (-0.5, -0.5), (-7.9, -0.1),
+                   (-5.0, -0.5), (-5.5, -1.0)]:
         compare_nw_align(engine, oracle, *make_pool(rng, lens, related=True), go=go, ge=ge)
+    lens2 = [(m, int(rng.integers(1, 500))) for m in (1, 63, 64, 65, 300, 640, 1000, 1024)]
+    compare_nw_align(engine, oracle, *make_pool(rng, lens2, related=True), go=-5.5, ge=-0.5)
     compare_nw_align(engine, oracle, *make_pool(rng, lens, "ACGT", related=True), mode="dna")
     compare_nw_align(engine, oracle, *make_pool(rng, [(30, 30)] * 10 + [(200, 90)] * 3, "A"), mode="dna")  # tie storms
     # empty sides, both empty, and a pair beyond the batch kernel's limits (single-pair path)
@@ -194,8 +199,6 @@ def test_nw_batch_align_seed_segments(engine):
     for mode in (0, 1):
         sub, idx = scoring_arrays(gold["tables"][modes[mode]])
         for go, ge in sorted({(c["go"], c["ge"]) for c in gold["nw"]}):
-            if go != int(go) or ge != int(ge):
-                continue  # fractional penalties go through sa_nw (tests/test_gpu_seed_segments.py)
             cases = [c for c in gold["nw"] if c["mode"] == mode and (c["go"], c["ge"]) == (go, ge) and (c["s1"] or c["s2"])]
             if not cases:
                 continue

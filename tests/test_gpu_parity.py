@@ -160,6 +160,27 @@ def test_fractional_gap_penalties(engine, oracle, kind, go, ge):
     check(kind, engine, oracle, rand_seq(rng, 200, PROT24), rand_seq(rng, 300, PROT24), "protein", go, ge)
 
 
+def test_fractional_gaps_take_the_persistent_pipeline(engine, oracle):
+    """NW with -5.5 / -0.5 is one persistent launch for every rows-per-lane setting (the FLAG_FRAC instances), SW needs
+    no special instance at all (E and F are floored at 0, so a fractional penalty acts like its floor)."""
+    rng = np.random.default_rng(31)
+    x = rand_seq(rng, 3000, DNA)
+    y = mutate(rng, x, DNA, 0.1, 0.05, 0.05)
+    engine.set_option("persistent", 1)
+    for K in (1, 2, 4, 8, 0):
+        engine.set_tuning(K, 0)
+        for kind in ("nw", "sw"):
+            g = check(kind, engine, oracle, x, y, "dna", -5.5, -0.5)
+            assert g.n_launches == 1 and (K == 0 or g.rows_per_lane == K)
+    engine.set_tuning(0, 0)
+    engine.set_option("checkpoint_band", 2)
+    try:
+        g = check("nw", engine, oracle, x, y, "dna", -4.25, -1.75)
+        assert g.n_launches > 1
+    finally:
+        engine.set_option("checkpoint_band", 0)
+
+
 def test_fractional_gap_golden_scores(engine):
     import json
     from pathlib import Path

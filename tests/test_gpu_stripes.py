@@ -159,7 +159,7 @@ def test_stripes_protein_and_gaps(engine, oracle):
     rng = np.random.default_rng(43)
     x = rand_seq(rng, 1800, PROT20)
     y = mutate(rng, x, PROT20, 0.2, 0.05, 0.05)
-    for go, ge in ((-5.0, -1.0), (-11.0, -1.0), (-2.0, -2.0)):
+    for go, ge in ((-5.0, -1.0), (-11.0, -1.0), (-2.0, -2.0), (-5.5, -0.5), (-4.25, -1.75)):
         want = oracle.nw(x, y, "protein", go, ge)
         score, ops, _ = striped(engine, "nw", x, y, 3, "protein", go, ge, 256)
         assert score == want.score and np.array_equal(ops, want.ops)

@@ -1,7 +1,7 @@
 """Randomised GPU-vs-oracle parity of the many-pair entry points (sa_sw_batch, sa_sw_batch_align,
 sa_nw_batch_align, sa_lcs_batch_align, sa_sw_window_batch): random batch sizes, lengths around the
 row-group and kernel-limit edges (0, 63..65, 1023..1025, > the batch kernels' limits), alphabets,
-related / unrelated / tie-storm pairs, integral gap settings and code budgets that cut the batch into
+related / unrelated / tie-storm pairs, integral and fractional gap settings and code budgets that cut the batch into
 chunks.  `python tools/fuzz_gpu_batch.py SECONDS [SEED]`; stops at the first mismatch."""
 import sys
 import time
@@ -20,7 +20,8 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 eng, orc = sa.Engine(0), Oracle()
-GAPS = [(-5.0, -1.0), (-2.0, -2.0), (-11.0, -1.0), (-1.0, -3.0), (0.0, 0.0), (-3.0, 0.0), (-10.0, -1.0)]
+GAPS = [(-5.0, -1.0), (-2.0, -2.0), (-11.0, -1.0), (-1.0, -3.0), (0.0, 0.0), (-3.0, 0.0), (-10.0, -1.0), (-5.5, -0.5), (-4.25, -1.75),
+        (-0.5, -0.5), (-7.9, -0.1), (-5.0, -0.5)]
 EDGE = [0, 1, 2, 63, 64, 65, 127, 128, 129, 511, 512, 513, 1023, 1024]
 
 
