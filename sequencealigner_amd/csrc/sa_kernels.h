@@ -594,7 +594,7 @@ template <int KIND, int K, bool BND, int FLAGS>
 __device__ __forceinline__ bool run_block_p(Lane<KIND, K>& st, const FillArgs& a, const int s, const int Tb, const int lane,
                                             const char* ldsLane, const uint32_t (&xr)[K], int* dprow, int yb, int& ny,
                                             int2 (&pend)[HandoffDepth<KIND, K>::D], int& ibH, int& ibF, int& obH, int& obF,
-                                            const int2* rd, int2* wr, const int gen_r, const int gen_w, int* dbgc = nullptr) {
+                                            const int2* rd, int2* wr, int2* sink, const int gen_r, const int gen_w, int* dbgc = nullptr) {
   constexpr int D = HandoffDepth<KIND, K>::D;
   uint32_t* tdst = a.trace + (((size_t)(s - a.trace_s0) * a.W + (Tb >> 4)) * 64 + lane) * K;
 #pragma unroll
@@ -620,12 +620,14 @@ __device__ __forceinline__ bool run_block_p(Lane<KIND, K>& st, const FillArgs& a
     if (sub == 2) ny = a.yenc[Tb + 64 + lane];
     if (!(FLAGS & FLAG_NOTRACE)) store_trace<K>(tdst, tacc);
     tdst += 64 * K;
-    // The out-buffers are rotated once per step, through the whole strip: lane L holds the record of step
-    // Ts + L - 48, i.e. of the bottom-row column Ts + L - 111 (index p = Ts + L - 47).  Lanes 48..63 hold the 16
-    // new ones; interior blocks let every lane store (the older records are rewritten with the values they already
-    // have) so that the store sits on every path and the compiler can count it in its waits; the first block
-    // of a strip (always a BND instance) must not: its lower lanes hold steps before the strip began.
-    if (!BND || lane >= 48) ho_store(wr + Ts, obH, obF, gen_w);
+    // The out-buffers are rotated once per step: lane 48 + u holds the record of step Ts + u, i.e. of the
+    // bottom-row column Ts + u - 63 (index p = Ts + u + 1).  Interior blocks let every lane store -- the lower 48 into
+    // the slot's unused entry 0 (`sink`) -- so that the store sits on every path and the compiler can count it in
+    // its waits; boundary blocks predicate it.
+    if (!BND)
+      ho_store(lane >= 48 ? wr + Ts : sink, obH, obF, gen_w);
+    else if (lane >= 48)
+      ho_store(wr + Ts, obH, obF, gen_w);
   }
   return true;
 }
@@ -688,8 +690,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
     }
     // slot and generation of the records this strip reads / writes (see ho_store); matrix row 0 is "strip -1"
     const int gen_r = ho_gen((s / a.ring) % 3), gen_w = ho_gen(((s + 1) / a.ring) % 3);
-    const int2* rd = a.bot2 + (size_t)(s % a.ring) * a.NP + 64 + lane;          // lanes 0..15 of sub-block Ts: column Ts + lane
-    int2* wr = a.bot2 + (size_t)((s + 1) % a.ring) * a.NP + 1 + (lane - 48);    // lanes 48..63 of sub-block Ts: step Ts + lane - 48
+    // lanes 0..15 of sub-block Ts read the record of column Ts + lane; the other lanes read lane 15's again (same cache
+    // line: no traffic of their own, and the load stays one unpredicated instruction)
+    const int2* rd = a.bot2 + (size_t)(s % a.ring) * a.NP + 64 + min(lane, 15);
+    // lanes 48..63 of sub-block Ts write the record of step Ts + lane - 48; in interior blocks, where the store is
+    // unpredicated, the other lanes write into the slot's entry 0, which nobody reads
+    int2* const wr_slot_base = a.bot2 + (size_t)((s + 1) % a.ring) * a.NP;
+    int2* wr = wr_slot_base + 1 + (lane - 48);
     int2 pend[HandoffDepth<KIND, K>::D];
 #pragma unroll
     for (int j = 0; j < HandoffDepth<KIND, K>::D; ++j) pend[j] = ho_load(rd + 16 * j);
@@ -709,8 +716,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
       const int Tb = 64 * b;
       const int yb = YSCALE ? ny * G::ROWB : ny;
       const bool interior = (Tb >= 64) && (Tb + 63 < a.n);
-      const bool ok = interior ? run_block_p<KIND, K, false, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow, yb, ny, pend, ibH, ibF, obH, obF, rd, wr, gen_r, gen_w, dbgc)
-                               : run_block_p<KIND, K, true, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow, yb, ny, pend, ibH, ibF, obH, obF, rd, wr, gen_r, gen_w, dbgc);
+      const bool ok = interior ? run_block_p<KIND, K, false, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow, yb, ny, pend, ibH, ibF, obH, obF, rd, wr, wr_slot_base, gen_r, gen_w, dbgc)
+                               : run_block_p<KIND, K, true, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow, yb, ny, pend, ibH, ibF, obH, obF, rd, wr, wr_slot_base, gen_r, gen_w, dbgc);
       dead = !ok;
     }
 #ifdef SA_DEBUG_HANDOFF
