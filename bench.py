@@ -66,7 +66,11 @@ def launch_ranks(n, argv):
 OPS_PER_CELL = {"nw": 12, "sw": 14, "lcs": 6}
 OPS_CODE = {"nw": 4, "sw": 4, "lcs": 2}  # of which: the direction code (cmp/select/pack), absent from code-free passes
 HBM_BYTES_PER_CELL = 0.25
-VALU_PEAK_TOPS = 39.3  # 256 CU x 64 lanes x 2.4 GHz int32 lane-ops/s (measured: profiles/probe_valu_r01.txt)
+VALU_PEAK_TOPS = 39.3  # 256 CU x 4 SIMD x 16 lanes x 2.4 GHz int32 lane-ops/s: one wave64 instruction per 4 cycles per SIMD
+# Measured with inline-asm streams (profiles/r02_probe_valu_asm.txt): v_max_i32 / v_max3_i32 / SDWA / DPP / v_alignbit issue at
+# 4.25 cycles (36.9 T) at any occupancy, v_add_u32 at 3.0 (52 T) and v_and_b32 at 2.3 (68 T) once a SIMD holds two waves.  For the
+# NW recurrence's 12 ops (5 adds, 7 four-cycle ops) that mix gives 12 / (5 / 52.3 + 7 / 36.9) = 42.1 T: quoted beside `frac`.
+VALU_PEAK_MIX_TOPS = {"nw": 42.1, "sw": 41.2, "lcs": 38.8}  # SW: 5 adds + 9 four-cycle ops; LCS: 1 add + 5
 HBM_PEAK_GBS = 8000.0
 
 
@@ -270,9 +274,10 @@ def batch_pmc_traffic(workload, per_rank):
 def pmc_traffic(args, m, n, world, res):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot
     run inside the timed program): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction), valid for the
-    workload and schedule the profile was taken on, else null."""
-    f = Path(__file__).resolve().parent / "profiles" / "r01_nw1m_pmc_v5_persistent.json"
-    if world != 1 or args.kind != "nw" or (m, n) != (1000000, 999747) or res.n_launches != 1 or not f.exists():
+    workload and schedule the profile was taken on (tools/profile_r02.sh), else null."""
+    tag = {(1000000, 999747): "1m", (100000, 100085): "100k"}.get((m, n))
+    f = Path(__file__).resolve().parent / "profiles" / f"r02_nw{tag}_pmc.json"
+    if world != 1 or args.kind != "nw" or args.unrelated or tag is None or res.n_launches != 1 or not f.exists():
         return None
     return json.loads(f.read_text())["derived"]["hbm_traffic_bytes_per_launch"]
 
@@ -484,6 +489,10 @@ def main():
                 "peak": VALU_PEAK_TOPS,
                 "unit": "T int32 lane-ops/s",
                 "frac": round(achieved / VALU_PEAK_TOPS, 4),
+                "frac_of_mix_weighted_peak": round(achieved / VALU_PEAK_MIX_TOPS[args.kind], 4),
+                "peak_note": "peak = one wave64 int32 instruction per 4 cycles per SIMD at 2.4 GHz (SURVEY 8d); the probe in profiles/r02_probe_valu_asm.txt "
+                             "measures 36.9 T for max / max3 / SDWA / DPP, 52 T for v_add_u32 with >= 2 waves per SIMD: mix-weighted peak for this recurrence "
+                             f"{VALU_PEAK_MIX_TOPS[args.kind]} T",
                 "traffic": pmc_traffic(args, m, n, world, res),
                 "traffic_note": "HBM bytes per launch, WRITE_SIZE + 2 x FETCH_SIZE of the PMC passes under profiles/; "
                                 "algorithmic: 0.25 B/cell trace + 16 B per strip column of bottom-row hand-off",

@@ -822,7 +822,7 @@ struct TraceArgs {
   const uint32_t* trace;
   const int* sw_best;                  // SW: best score (device)
   const unsigned long long* sw_pos;    // SW: (i<<32)|j of the end cell (device)
-  uint8_t* ops;                        // out: one byte per move
+  unsigned long long* ops2;            // out: the moves, two bits each, 32 to a word (expand_ops makes bytes of them)
   long long* hdr;                      // out: n_ops, end_i, end_j, start_i, start_j
 };
 
@@ -879,14 +879,161 @@ __device__ __forceinline__ uint32_t window_code(const TraceWindow& w, int q, boo
 // the window path needs 64 rows above and room for 16 columns of drift on both sides
 __device__ __forceinline__ bool window_ok(int i, int j) { return i >= 64 && j >= 81; }
 
-constexpr int kTraceStage = 32768;  // bytes of moves staged in LDS between flushes
+constexpr int kTraceStageWords = 4096;  // 64-bit words of packed moves (32 each) staged in LDS between flushes
+
+// The moves leave the walker packed two bits each (0 diagonal, 1 left, 2 up), 32 to a 64-bit word, in traceback
+// order; expand_ops turns them into the one-byte-per-move list of the C-ABI.  Everything here is wave-uniform and
+// lives in scalar registers: a move costs a shift and an OR, a diagonal run of any length one addition.
+struct MoveEmitter {
+  unsigned long long acc;   // the word being filled
+  int k;                    // moves in acc, 0..31
+  int staged;               // complete words waiting in LDS
+  long long words_out;      // complete words already in global memory
+  unsigned long long* stage;
+  unsigned long long* out;
+  int lane;
+
+  __device__ __forceinline__ void push_word() {
+    stage[staged] = acc;  // every lane stores the same word to the same place: no divergent branch
+    ++staged;
+    acc = 0;
+    k = 0;
+    if (staged == kTraceStageWords) flush();
+  }
+  __device__ __forceinline__ void flush() {
+    wave_lds_fence();  // the staged words were written by lane 0
+    for (int q = lane; q < staged; q += 64) out[words_out + q] = stage[q];
+    words_out += staged;
+    staged = 0;
+    wave_lds_fence();  // later staging writes stay behind these reads
+  }
+  __device__ __forceinline__ void emit(uint32_t op) {
+    acc |= (unsigned long long)op << (2 * k);
+    if (++k == 32) push_word();
+  }
+  __device__ __forceinline__ void emit_run(uint32_t op, long long L) {
+    const unsigned long long pat = op == 0 ? 0ull : (op == 1 ? 0x5555555555555555ull : 0xAAAAAAAAAAAAAAAAull);
+    while (L > 0) {
+      const int take = (int)min((long long)(32 - k), L);
+      const unsigned long long bits = take == 32 ? pat : (pat & ((1ull << (2 * take)) - 1ull));
+      acc |= bits << (2 * k);
+      k += take;
+      L -= take;
+      if (k == 32) push_word();
+    }
+  }
+  __device__ __forceinline__ long long total() const { return (words_out + staged) * 32 + k; }
+  __device__ __forceinline__ void finish() {  // the partial word goes out too (the next band continues it)
+    flush();
+    if (lane == 0) out[words_out] = acc;
+  }
+};
+
+// The scalar walk through one 64-row window (traceback_walk).  State, all wave-uniform: dcur = rows of the window
+// already left behind, o = drift from the window's diagonal (-16..15), k / acc = the emitter's word being filled.
+// dm_lo / dm_hi: lane q holds the 64-row mask "the cell at drift q - 16 is a diagonal move"; Flo / Fhi: lane r
+// holds row r's 32 two-bit codes (drift -16 first).  Per round: the diagonal run from (dcur, o) is the run of ones
+// in mask[o] from bit dcur (s_ff1 of its complement) and costs one addition to k (zero codes); then ONE gap move:
+// its code comes out of the row's scalar copy, goes into acc, and moves dcur / o.  Leaves -- with everything
+// consistent, the caller looks at k, dcur, o and the returned code -- when a word is full (k >= 32), the window is
+// done (dcur >= 64), an SW stop code (3) turns up, or the path drifted out of the window.  vcc is the 64-bit scratch pair
+// (inline asm cannot name the halves of a 64-bit operand).
+__device__ __forceinline__ uint32_t walk_rounds(const bool tagged, const uint32_t dm_lo, const uint32_t dm_hi, const uint32_t Flo,
+                                                const uint32_t Fhi, int& dcur, int& o, int& k, unsigned long long& acc) {
+  uint32_t c = 0, t0, t1, L;
+  if (tagged) {
+    asm volatile(
+        "Ltop_%=:\n\t"
+        "s_add_i32 %[t0], %[o], 16\n\t"
+        "v_readlane_b32 vcc_hi, %[dmhi], %[t0]\n\t"
+        "v_readlane_b32 vcc_lo, %[dmlo], %[t0]\n\t"
+        "s_lshr_b64 vcc, vcc, %[d]\n\t"
+        "s_not_b64 vcc, vcc\n\t"
+        "s_ff1_i32_b64 %[L], vcc\n\t"
+        "s_sub_i32 %[t1], 64, %[d]\n\t"
+        "s_min_u32 %[L], %[L], %[t1]\n\t"
+        "s_add_i32 %[k], %[k], %[L]\n\t"
+        "s_add_i32 %[d], %[d], %[L]\n\t"
+        "s_cmp_ge_i32 %[k], 32\n\t"
+        "s_cbranch_scc1 Lout_%=\n\t"
+        "s_cmp_ge_i32 %[d], 64\n\t"
+        "s_cbranch_scc1 Lout_%=\n\t"
+        "v_readlane_b32 vcc_hi, %[fhi], %[d]\n\t"
+        "v_readlane_b32 vcc_lo, %[flo], %[d]\n\t"
+        "s_lshl_b32 %[t0], %[t0], 1\n\t"
+        "s_lshr_b64 vcc, vcc, %[t0]\n\t"
+        "s_and_b32 %[c], vcc_lo, 3\n\t"
+        "s_cmp_eq_u32 %[c], 3\n\t"
+        "s_cbranch_scc1 Lout_%=\n\t"
+        "s_sub_i32 %[t1], 2, %[c]\n\t"          // op: 1 left, 2 up
+        "s_lshl_b32 %[t0], %[k], 1\n\t"
+        "s_mov_b32 vcc_hi, 0\n\t"
+        "s_mov_b32 vcc_lo, %[t1]\n\t"
+        "s_lshl_b64 vcc, vcc, %[t0]\n\t"
+        "s_or_b64 %[acc], %[acc], vcc\n\t"
+        "s_add_i32 %[k], %[k], 1\n\t"
+        "s_lshr_b32 %[t1], %[t1], 1\n\t"        // 1 for an up move
+        "s_add_i32 %[d], %[d], %[t1]\n\t"
+        "s_lshl_b32 %[t1], %[t1], 1\n\t"
+        "s_add_i32 %[o], %[o], %[t1]\n\t"
+        "s_add_i32 %[o], %[o], -1\n\t"
+        "s_add_i32 %[t0], %[o], 16\n\t"
+        "s_cmp_lt_u32 %[t0], 32\n\t"
+        "s_cbranch_scc1 Ltop_%=\n\t"
+        "Lout_%=:\n\t"
+        : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [c] "+s"(c), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L)
+        : [dmlo] "v"(dm_lo), [dmhi] "v"(dm_hi), [flo] "v"(Flo), [fhi] "v"(Fhi)
+        : "scc", "vcc");
+  } else {  // LCS: codes 3 diagonal, 2 up, 1 left are the ops themselves; there is no stop code
+    asm volatile(
+        "Ltop_%=:\n\t"
+        "s_add_i32 %[t0], %[o], 16\n\t"
+        "v_readlane_b32 vcc_hi, %[dmhi], %[t0]\n\t"
+        "v_readlane_b32 vcc_lo, %[dmlo], %[t0]\n\t"
+        "s_lshr_b64 vcc, vcc, %[d]\n\t"
+        "s_not_b64 vcc, vcc\n\t"
+        "s_ff1_i32_b64 %[L], vcc\n\t"
+        "s_sub_i32 %[t1], 64, %[d]\n\t"
+        "s_min_u32 %[L], %[L], %[t1]\n\t"
+        "s_add_i32 %[k], %[k], %[L]\n\t"
+        "s_add_i32 %[d], %[d], %[L]\n\t"
+        "s_cmp_ge_i32 %[k], 32\n\t"
+        "s_cbranch_scc1 Lout_%=\n\t"
+        "s_cmp_ge_i32 %[d], 64\n\t"
+        "s_cbranch_scc1 Lout_%=\n\t"
+        "v_readlane_b32 vcc_hi, %[fhi], %[d]\n\t"
+        "v_readlane_b32 vcc_lo, %[flo], %[d]\n\t"
+        "s_lshl_b32 %[t0], %[t0], 1\n\t"
+        "s_lshr_b64 vcc, vcc, %[t0]\n\t"
+        "s_and_b32 %[t1], vcc_lo, 3\n\t"          // op: 1 left, 2 up
+        "s_lshl_b32 %[t0], %[k], 1\n\t"
+        "s_mov_b32 vcc_hi, 0\n\t"
+        "s_mov_b32 vcc_lo, %[t1]\n\t"
+        "s_lshl_b64 vcc, vcc, %[t0]\n\t"
+        "s_or_b64 %[acc], %[acc], vcc\n\t"
+        "s_add_i32 %[k], %[k], 1\n\t"
+        "s_lshr_b32 %[t1], %[t1], 1\n\t"
+        "s_add_i32 %[d], %[d], %[t1]\n\t"
+        "s_lshl_b32 %[t1], %[t1], 1\n\t"
+        "s_add_i32 %[o], %[o], %[t1]\n\t"
+        "s_add_i32 %[o], %[o], -1\n\t"
+        "s_add_i32 %[t0], %[o], 16\n\t"
+        "s_cmp_lt_u32 %[t0], 32\n\t"
+        "s_cbranch_scc1 Ltop_%=\n\t"
+        "Lout_%=:\n\t"
+        : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L)
+        : [dmlo] "v"(dm_lo), [dmhi] "v"(dm_hi), [flo] "v"(Flo), [fhi] "v"(Fhi)
+        : "scc", "vcc");
+  }
+  return c;
+}
 
 __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
-  // The moves are staged in LDS and written out in bulk: with no global stores inside the walk, the
+  // The packed moves are staged in LDS and written out in bulk: with no global stores inside the walk, the
   // only vector-memory operations in flight are the loads of the NEXT window, so waiting for them
   // at the top of the next round (vmcnt counts loads and stores together, in order) waits for
   // nothing else -- the prefetch really overlaps the walk through the current window.
-  __shared__ uint8_t stage[kTraceStage];
+  __shared__ unsigned long long stage[kTraceStageWords];
   const int d = threadIdx.x;
   const bool tagged = a.kind != KIND_LCS;
   int lgK = 0;
@@ -904,27 +1051,34 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
       j = (int)(p & 0xffffffffu);
     }
   }
+  i = __builtin_amdgcn_readfirstlane(i);
+  j = __builtin_amdgcn_readfirstlane(j);
   if (d == 0) {
     a.hdr[1] = i;
     a.hdr[2] = j;
   }
-  long long nops = a.nops0;     // moves emitted so far
-  long long flushed = a.nops0;  // ... of which ops[0, flushed) have reached global memory
+  MoveEmitter em;
+  em.stage = stage;
+  em.out = a.ops2;
+  em.lane = d;
+  em.staged = 0;
+  em.words_out = a.nops0 >> 5;  // the walks over the bands below left nops0 moves, the last word partial
+  em.k = (int)(a.nops0 & 31);
+  em.acc = 0;
+  if (em.k) {
+    const unsigned long long w = a.ops2[em.words_out];
+    em.acc = (((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(w >> 32)) << 32) |
+              (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)w)) & ((1ull << (2 * em.k)) - 1ull);
+  }
   const int i_min = a.i_min;
-  auto flush = [&]() {
-    wave_lds_fence();  // the staged bytes were written by other lanes
-    const int cnt = (int)(nops - flushed);
-    for (int q = d; q < cnt; q += 64) a.ops[flushed + q] = stage[q];
-    flushed = nops;
-    wave_lds_fence();  // later staging writes stay behind these reads
-  };
+  // raw codes: NW / SW store the winner's tag (M 2, E 1, F 0, SW zero cell 3), LCS diagonal 3, up 2, left 1
+  const uint32_t rawD = tagged ? 2u : 3u;
   bool have = false;  // nw holds the window of entry cell (pi, pj)
   int pi = 0, pj = 0;
   TraceWindow nw{0, 0, 0, 0};
   bool stopped = false;
   while (i > i_min && j > 0 && !stopped) {
-    if (nops - flushed > kTraceStage - 256) flush();
-    const int sbase = (int)(nops - flushed);
+    if (em.staged > kTraceStageWords - 16) em.flush();  // a window adds at most 4 words
     if (window_ok(i - i_min, j)) {
       // ---- fast path: 64 rows per memory round trip, the next window already in flight ----
       if (!(have && pi == i && abs(j - pj) <= 14)) {
@@ -945,69 +1099,47 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
         pj = j - 64;
         nw = load_trace_window(a.trace, pi - i_min, pj, d, lgK, a.W);
       }
-      int dcur = 0, emitted = 0;
       const int o_in = o;
       // The lane's 32 codes around its own cell of the entry diagonal, as one 64-bit value: the code
-      // at drift o (-16..15) is bits [2(o+16), 2(o+16)+1].  Two funnel shifts per window; every step
-      // of the walk is then a 64-bit shift and a compare.
+      // at drift o (-16..15) is bits [2(o+16), 2(o+16)+1] (two funnel shifts per window).
       const int sh0 = 2 * (w.pb - 16);
-      const unsigned long long F = ((unsigned long long)__builtin_amdgcn_alignbit(w.w2, w.w1, sh0) << 32) |
-                                   (unsigned long long)__builtin_amdgcn_alignbit(w.w1, w.w0, sh0);
-      // raw codes: NW / SW store the winner's tag (M 2, E 1, F 0, SW zero cell 3), LCS diagonal 3, up 2, left 1
-      const uint32_t rawD = tagged ? 2u : 3u, rawU = tagged ? 0u : 2u;
-      while (dcur < 64) {
-        if (o < -16 || o > 15) break;  // drifted out of the window: re-centre
-        const uint32_t rM = (uint32_t)(F >> (2 * (o + 16))) & 3u;  // the lane's cell on the current diagonal
-        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)rM, dcur);
-        if (tagged && r0 == 3u) {  // SW stop cell
+      const uint32_t Flo = __builtin_amdgcn_alignbit(w.w1, w.w0, sh0), Fhi = __builtin_amdgcn_alignbit(w.w2, w.w1, sh0);
+      // Walk the window on the scalar unit.  diagmask[q] (lane q of dm_lo / dm_hi, q = drift + 16) says for which of
+      // the 64 rows the cell at that drift is a diagonal move: one ballot per drift, 32 per window, all lanes at
+      // once.  Then every round of the loop below is "the diagonal run from here (a shift and a find-first-zero on
+      // that mask, possibly empty), then ONE gap move (the row's codes sit in two scalar registers: a shift, an
+      // OR into the emitter)" -- no vector work and no memory access per move, one round per gap move.
+      uint32_t dm_lo = 0, dm_hi = 0;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) {
+        const uint32_t cq = ((q < 16 ? Flo : Fhi) >> (2 * (q & 15))) & 3u;
+        const unsigned long long bq = __ballot(cq == rawD);
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(dm_lo) : "s"((uint32_t)bq), "n"(q));
+        asm("v_writelane_b32 %0, %1, %2" : "+v"(dm_hi) : "s"((uint32_t)(bq >> 32)), "n"(q));
+      }
+      int dcur = 0;
+      unsigned long long acc = em.acc;  // the emitter's state in scalars of our own for the duration of the window
+      int k = em.k, staged = em.staged;
+      while (true) {
+        // One round = the diagonal run from (dcur, o), then one gap move; rounds follow each other inside the
+        // assembly until something rare happens (see walk_rounds).  Written by hand because the compiled loop
+        // took four taken branches per round, and a lone wave pays ~50 cycles of instruction fetch for each.
+        const uint32_t c = walk_rounds(tagged, dm_lo, dm_hi, Flo, Fhi, dcur, o, k, acc);
+        while (k >= 32) {  // all lanes store the same word to the same place: no divergence
+          stage[staged++] = acc;
+          acc = 0;
+          k -= 32;
+        }
+        if (dcur >= 64) break;
+        if (c == 3u) {  // SW stop cell
           stopped = true;
           break;
         }
-        int L;
-        if (r0 == rawD) {  // diagonal run: rows dcur.. whose cell on this diagonal is a diagonal move
-          const unsigned long long run = __ballot(rM == rawD) >> dcur;
-          L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);
-          if (d >= dcur && d < dcur + L) stage[sbase + emitted + (d - dcur)] = 0;
-          dcur += L;
-          // The cell that ended the run is in the window too: take its move now (isolated indels and LCS
-          // mismatches are runs of one), instead of spending a whole iteration of this serial loop on it.
-          if (dcur < 64) {
-            const uint32_t c1 = (uint32_t)__builtin_amdgcn_readlane((int)rM, dcur);
-            if (c1 == rawU) {
-              if (d == 0) stage[sbase + emitted + L] = 2;
-              ++L;
-              ++dcur;
-              ++o;
-            } else if (c1 == 1u) {
-              if (d == 0) stage[sbase + emitted + L] = 1;
-              ++L;
-              --o;
-            }
-          }
-        } else if (r0 == rawU) {  // up run: row dcur + k is entered at drift o + k
-          const int ol = o + (d - dcur);
-          const bool in = d >= dcur && ol <= 15;
-          const uint32_t rF = (uint32_t)(F >> (2 * ((in ? ol : 0) + 16))) & 3u;
-          const unsigned long long run = __ballot(in && rF == rawU) >> dcur;
-          L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);
-          if (d >= dcur && d < dcur + L) stage[sbase + emitted + (d - dcur)] = 2;
-          dcur += L;
-          o += L;
-        } else {  // left run inside row dcur: lane k looks k cells to the left
-          const unsigned long long Fd = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(F >> 32), dcur) << 32) |
-                                        (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)F, dcur);
-          const int ol = o - d;
-          const bool in = ol >= -16;
-          const uint32_t rL = (uint32_t)(Fd >> (2 * ((in ? ol : 0) + 16))) & 3u;
-          const unsigned long long run = __ballot(in && rL == 1u);
-          L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);
-          if (d < L) stage[sbase + emitted + d] = 1;
-          o -= L;
-        }
-        emitted += L;
-        if (emitted > 128) break;  // staging room of one round
+        if (o < -16 || o > 15) break;  // drifted out of the window: re-centre
       }
-      nops += emitted;
+      em.acc = acc;
+      em.k = k;
+      em.staged = staged;
       if (dcur == 0 && o == o_in && !stopped) have = false;  // out of the window at once: take the generic path below
       i -= dcur;
       j = j0 - dcur + o;
@@ -1031,8 +1163,7 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
     else
       run = __ballot(cF == 2u);
     const int L = (~run == 0ull) ? 64 : __builtin_ctzll(~run);
-    if (d < L) stage[sbase + d] = (uint8_t)c0;
-    nops += L;
+    em.emit_run(c0, L);
     if (c0 != 1u) i -= L;
     if (c0 != 2u) j -= L;
     // a diagonal run that ends inside the window also tells us the next move (the code of the
@@ -1040,36 +1171,39 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
     if (c0 == 0u && L < 64) {
       const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)cM, L);
       if (cn == 1u || cn == 2u) {
-        if (d == 0) stage[sbase + L] = (uint8_t)cn;
-        nops += 1;
+        em.emit(cn);
         if (cn == 1u) --j; else --i;
       }
     }
   }
-  flush();
   if (i > 0 && j > 0) {
     // NW / LCS: the walk reached the top row of a recomputed band; the host continues with the band
     // above from (i, j).  SW: it stopped at its 'X' cell.
   } else if (a.kind != KIND_SW && a.stop_at_col0) {
     if (i == 0) {  // row 0 of the matrix: left moves to the stripe's edge
-      for (long long q = d; q < j; q += 64) a.ops[nops + q] = 1;
-      nops += j;
+      em.emit_run(1u, j);
       j = 0;
     }
   } else if (a.kind != KIND_SW) {
     // border walk: row 0 is all 'E'/'e' (main.cpp:727-728), column 0 all 'F'/'f' (main.cpp:609-616);
     // LCS drains the same way (main.cpp:1623-1634)
-    const uint8_t code = (i == 0) ? 1 : 2;
-    const long long rest = (i == 0) ? j : i;
-    for (long long q = d; q < rest; q += 64) a.ops[nops + q] = code;
-    nops += rest;
+    em.emit_run((i == 0) ? 1u : 2u, (i == 0) ? j : i);
     i = j = 0;
   }
+  const long long nops = em.total();
+  em.finish();
   if (d == 0) {
     a.hdr[0] = nops;
     a.hdr[3] = i;
     a.hdr[4] = j;
   }
+}
+
+// packed moves -> one byte per move (the C-ABI's op list); hdr[0] = number of moves
+__global__ void expand_ops(const unsigned long long* __restrict__ ops2, uint8_t* __restrict__ ops, const long long* __restrict__ hdr) {
+  const long long n = hdr[0];
+  for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x)
+    ops[q] = (uint8_t)((ops2[q >> 5] >> (2 * (q & 31))) & 3ull);
 }
 
 }  // namespace sa

@@ -151,6 +151,15 @@ void release(Buf& b) {
   b.cap = 0;
 }
 
+// ctx->ops: [0, m + n + 64) one byte per move (what goes back to the host), then the walker's packed moves
+size_t ops_bytes_offset(int m, int n) { return ((size_t)m + n + 64 + 255) & ~size_t(255); }
+
+void launch_expand_ops(sa_ctx* ctx, int m, int n, long long n_max, const long long* d_hdr) {
+  const int blocks = (int)std::max<long long>(1, std::min<long long>((n_max + 255) / 256, 4096));
+  hipLaunchKernelGGL(expand_ops, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned long long*)((char*)ctx->ops.p + ops_bytes_offset(m, n)),
+                     (uint8_t*)ctx->ops.p, d_hdr);
+}
+
 // int + double truncated back to int, as every "score + GAP" of the reference (main.cpp:603).
 inline int add_gap(int v, double g) { return (int)((double)v + g); }
 
@@ -542,7 +551,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   if ((rc = ensure(ctx, ctx->small, 256))) return rc;
   const size_t pbuf_ints = (size_t)S + 64 + (size_t)n_chunks;
   if (persist && (rc = ensure(ctx, ctx->pbuf, pbuf_ints * 4))) return rc;
-  if ((rc = ensure(ctx, ctx->ops, (size_t)m + n + 64))) return rc;
+  if ((rc = ensure(ctx, ctx->ops, ops_bytes_offset(m, n) + ((size_t)m + n) / 4 + 1024))) return rc;  // one byte per move | packed moves
   if (kind != KIND_LCS || lprof) {
     if ((rc = ensure(ctx, ctx->prof, (size_t)S * alpha * 64 * PW * 4))) return rc;
     if ((rc = ensure(ctx, ctx->sub, 32 * 32))) return rc;
@@ -872,7 +881,7 @@ int traceback_ckpt(sa_ctx* ctx, int start_i, int start_j, sa_result* out) {
     t.trace = (const uint32_t*)ctx->trace.p;
     t.sw_best = (const int*)ctx->small.p;
     t.sw_pos = (const unsigned long long*)((char*)ctx->small.p + 8);
-    t.ops = (uint8_t*)ctx->ops.p;
+    t.ops2 = (unsigned long long*)((char*)ctx->ops.p + ops_bytes_offset(m, n));
     t.hdr = d_hdr;
     hipLaunchKernelGGL(traceback_walk, dim3(1), dim3(64), 0, st, t);
     HIPCK(ctx, hipGetLastError());
@@ -895,6 +904,7 @@ int traceback_ckpt(sa_ctx* ctx, int start_i, int start_j, sa_result* out) {
   if (nops > 0) {
     out->ops = (uint8_t*)malloc((size_t)nops);
     if (!out->ops) return fail(ctx, SA_ERR_NOMEM, "host malloc of %lld ops failed", nops);
+    launch_expand_ops(ctx, m, n, nops, d_hdr);
     HIPCK(ctx, hipMemcpyAsync(out->ops, ctx->ops.p, (size_t)nops, hipMemcpyDeviceToHost, st));
   }
   HIPCK(ctx, hipEventRecord(ctx->ev[3], st));
@@ -933,9 +943,10 @@ int traceback_impl(sa_ctx* ctx, int start_i, int start_j, bool want_tb, sa_resul
     t.trace = (const uint32_t*)ctx->trace.p;
     t.sw_best = d_score;
     t.sw_pos = d_pos;
-    t.ops = (uint8_t*)ctx->ops.p;
+    t.ops2 = (unsigned long long*)((char*)ctx->ops.p + ops_bytes_offset(m, n));
     t.hdr = d_hdr;
     hipLaunchKernelGGL(traceback_walk, dim3(1), dim3(64), 0, st, t);
+    launch_expand_ops(ctx, m, n, (long long)m + n, d_hdr);
     HIPCK(ctx, hipGetLastError());
     HIPCK(ctx, hipMemcpyAsync(h_hdr, d_hdr, sizeof h_hdr, hipMemcpyDeviceToHost, st));
   }
