@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <fstream>
 #include <iomanip>
@@ -131,6 +132,24 @@ bool write_path(const std::string& file, const sah_job& j, bool forward) {
 void write_plain_alignment(std::ostream& os, const std::string& id1, const std::string& id2, const std::string& a1,
                            const std::string& a2) {  // main.cpp:319-329: unwrapped lines
   os << '>' << id1 << '\n' << a1 << '\n' << '>' << id2 << '\n' << a2 << '\n';
+}
+
+// The reference redraws a progress bar every 100 rows of its fill loop under --verbose (showProgressBar,
+// main.cpp:159-201; call sites :757-761, :1130-1136, :1589-1591), each redraw starting with '\r'.  Here the fill is
+// one GPU launch, so only the last state is drawn -- what a terminal shows once the reference's loop is through:
+// the full bar, 100 %, m/m, the elapsed time since the first bar of the process and an ETA of 00:00.
+void final_progress_bar(int64_t m) {
+  if (m <= 0) return;  // the reference's loop body never runs
+  static const auto start_time = std::chrono::steady_clock::now();
+  const long elapsed = (long)std::chrono::duration_cast<std::chrono::seconds>(std::chrono::steady_clock::now() - start_time).count();
+  auto hms = [](long secs) {
+    std::ostringstream os;
+    if (secs / 3600) os << secs / 3600 << ":";
+    os << std::setw(2) << std::setfill('0') << (secs % 3600) / 60 << ":" << std::setw(2) << std::setfill('0') << secs % 60;
+    return os.str();
+  };
+  std::cout << "\r[" << std::string(100, '=') << "] " << std::setw(3) << 100 << "% " << m << "/" << m << " Elapsed: " << hms(elapsed)
+            << " ETA: " << hms(0) << std::flush;
 }
 
 void print_colored(const std::string& a, const std::string& b, std::ostream& os) {  // main.cpp:356-414
@@ -342,7 +361,8 @@ int sah_write_global(const sah_job* jp) {
   const double coverage = double(total - al.gaps) / total;
   const std::string acc1 = accession(j.header1, j.mode), acc2 = accession(j.header2, j.mode);
   const std::string g1 = gene_symbol(j.header1, j.mode), g2 = gene_symbol(j.header2, j.mode);
-  if (j.verbose) {  // main.cpp:858-873
+  if (j.verbose) {  // main.cpp:757-761 (progress), :858-873
+    final_progress_bar(j.m);
     std::cout << "\n\nGlobal Alignment Score: " << j.score << "\n"
               << "Gap Open: " << j.gap_open << "\nGap Extend: " << j.gap_extend << "\n"
               << "Matches: " << al.matches << "\nGaps:    " << al.gaps << "\nTotal:   " << total << "\n"
@@ -405,7 +425,8 @@ int sah_write_local(const sah_job* jp) {
   const double coverage = total > 0 ? double(total - al.gaps) / total : 0.0;
   const std::string acc1 = accession(j.header1, j.mode), acc2 = accession(j.header2, j.mode);
   const std::string g1 = gene_symbol(j.header1, j.mode), g2 = gene_symbol(j.header2, j.mode);
-  if (j.verbose) {  // main.cpp:1490-1511
+  if (j.verbose) {  // main.cpp:1130-1136 (progress), :1490-1511
+    final_progress_bar(j.m);
     std::cout << "\n\nLocal Alignment Score: " << j.score << "\nGap Open: " << j.gap_open << "\nGap Extend: " << j.gap_extend
               << "\n";
     if (total > 0)
@@ -486,7 +507,9 @@ int sah_write_lcs(const sah_job* jp) {
       dump_int_matrix(out + "/lcs_dp_lengths", j.dp, j.m + 1, j.n + 1, false);
     }
   }
-  if (j.verbose) {  // main.cpp:1694-1707
+  if (j.verbose) {  // main.cpp:1589-1593 (progress + newline), :1694-1707
+    final_progress_bar(j.m);
+    if (j.m > 0) std::cout << '\n';
     std::cout << "LCS Length: " << lcs.size() << "\n\n\nLCS Based Alignment:\n";
     print_colored(al.ax, al.ay, std::cout);
     std::cout << "\nLongest Common Subsequence String:\n";
