@@ -29,6 +29,7 @@
 //   NW  main.cpp:622-672   SW  main.cpp:939-1013   LCS  main.cpp:1577-1587
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <climits>
 #include <cstdint>
 
@@ -207,10 +208,16 @@ __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF,
   if (KIND != KIND_LCS || LPROF) {
     if (G::PW == 1) {
       pw[0] = *reinterpret_cast<const uint32_t*>(ldsLane + yv);
-    } else {
+    } else if (G::PW == 2) {
       const uint2 t = *reinterpret_cast<const uint2*>(ldsLane + yv);
       pw[0] = t.x;
       pw[G::PW - 1] = t.y;
+    } else {  // 16 rows per lane (LCS over a small alphabet): one ds_read_b128
+      const uint4 t = *reinterpret_cast<const uint4*>(ldsLane + yv);
+      pw[0] = t.x;
+      pw[1 % G::PW] = t.y;
+      pw[2 % G::PW] = t.z;
+      pw[3 % G::PW] = t.w;
     }
   }
   int diag = st.dprev;
@@ -232,6 +239,7 @@ __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF,
       const int dc = LPROF ? diag + (int)(int8_t)(pw[k / 4] >> (8 * (k & 3))) : ((xr[k] == (uint32_t)yv) ? diag + 6 : 0);
       const int ht = max(max(dc, up + 1), left);
       tacc[k] = __builtin_amdgcn_alignbit((uint32_t)ht, tacc[k], 2);
+      if (K >= 16 && !(FLAGS & FLAG_NOTRACE)) asm volatile("" : "+v"(tacc[k]));  // pack now (as for SW below): 16 x 16 live maxima do not fit
       // one v_and_or_b32; written as C the compiler splits it into an AND and two ORs per cell
       asm("v_and_or_b32 %0, %1, -4, 1" : "=v"(h) : "v"(ht));
       if (BND) h = act ? h : left;
@@ -597,8 +605,10 @@ __device__ __forceinline__ bool run_block_p(Lane<KIND, K>& st, const FillArgs& a
                                             const int2* rd, int2* wr, int2* sink, const int gen_r, const int gen_w, int* dbgc = nullptr) {
   constexpr int D = HandoffDepth<KIND, K>::D;
   uint32_t* tdst = a.trace + (((size_t)(s - a.trace_s0) * a.W + (Tb >> 4)) * 64 + lane) * K;
-#pragma unroll
-  for (int sub = 0; sub < 4; ++sub) {
+  // the four sub-blocks, expanded by hand: a loop this size (16 rows per lane) is not always unrolled in full, and
+  // pend[] then turns into a scratch array
+  auto sub_block = [&](auto subc) -> bool {
+    constexpr int sub = decltype(subc)::value;
     const int Ts = Tb + 16 * sub;
     uint32_t tacc[K], sbk[K], skp[K];
 #pragma unroll
@@ -628,8 +638,10 @@ __device__ __forceinline__ bool run_block_p(Lane<KIND, K>& st, const FillArgs& a
       ho_store(lane >= 48 ? wr + Ts : sink, obH, obF, gen_w);
     else if (lane >= 48)
       ho_store(wr + Ts, obH, obF, gen_w);
-  }
-  return true;
+    return true;
+  };
+  return sub_block(std::integral_constant<int, 0>()) && sub_block(std::integral_constant<int, 1>()) &&
+         sub_block(std::integral_constant<int, 2>()) && sub_block(std::integral_constant<int, 3>());
 }
 
 template <int KIND, int K, int FLAGS>

@@ -174,6 +174,9 @@ constexpr double kHandoffLatencyUs = 2.9;  // record store (sc1) -> visible to t
 // is max(critical path over launches, total work / 1024 SIMDs).
 // n_upstream: columns owned by the stripes to the left (multi-GPU): this stripe cannot start
 // before its first strip has crossed them, at one column per step.
+// rows per lane forced by sa_set_tuning; 16 exists only for the profile-driven persistent LCS, everything else takes 8 then
+int forced_K(const sa_ctx* ctx, bool has16 = false) { return (ctx->force_K == 16 && !has16) ? 8 : ctx->force_K; }
+
 Tuning choose_tuning(const sa_ctx* ctx, int kind, int64_t m, int64_t n, int64_t n_upstream = 0) {
   const double cell = kind == KIND_LCS ? 8.0 : (kind == KIND_SW ? 19.0 : 15.0);
   const double step0 = kind == KIND_LCS ? 9.0 : 13.0;
@@ -182,7 +185,7 @@ Tuning choose_tuning(const sa_ctx* ctx, int kind, int64_t m, int64_t n, int64_t 
   Tuning t{4, 256};
   for (int K : {1, 2, 4, 8}) {
     for (int C : {64, 128, 256, 512}) {
-      if (ctx->force_K && K != ctx->force_K) continue;
+      if (forced_K(ctx) && K != forced_K(ctx)) continue;
       if (ctx->force_C && C != ctx->force_C) continue;
       const double S = std::ceil((double)m / (64.0 * K));
       const double L = std::ceil((64.0 * S + n + 63) / C) + S;
@@ -196,7 +199,7 @@ Tuning choose_tuning(const sa_ctx* ctx, int kind, int64_t m, int64_t n, int64_t 
       }
     }
   }
-  if (ctx->force_K) t.K = ctx->force_K;
+  if (forced_K(ctx)) t.K = forced_K(ctx);
   if (ctx->force_C) t.C = ctx->force_C;
   return t;
 }
@@ -218,13 +221,16 @@ double pipeline_steps(double S, double waves, double n, double lag) {
 // Rows per lane for the persistent pipeline on one GPU: the schedule above priced with the measured
 // step cost (choose_stripe_K below).  E.g. 786 432 rows: K=8 gives 1536 strips = 2 rounds with half
 // the waves idle in the second, K=4 gives 3 full rounds of cheaper steps and wins by 10 %.
-int choose_persist_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n, bool lprof = false) {
-  if (ctx->force_K) return ctx->force_K;
+// The profile-driven LCS also has a 16-rows-per-lane instance: its cell is 5 instructions, so the unrolled block still
+// fits the instruction cache (the NW / SW one does not), and 1 Mb of rows becomes 977 strips = ONE round.
+int choose_persist_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n, bool lprof = false, bool has16 = false) {
+  if (ctx->force_K) return forced_K(ctx, has16);
   const double cell = kind == KIND_LCS ? (lprof ? 5.0 : 7.0) : (kind == KIND_SW ? 12.0 : 10.0);
   const double waves = 4.0 * ctx->n_cu * std::max(1, ctx->wps);
   double best = 1e300;
   int bestK = 1;
-  for (int K : {1, 2, 4, 8}) {
+  for (int K : {1, 2, 4, 8, 16}) {
+    if (K == 16 && !has16) continue;
     const double step = (cell * K + 18.0) * 4.0;
     const double S = std::ceil((double)m / (64.0 * K));
     const double est = pipeline_steps(S, waves, (double)n + 63.0, strip_lag(step)) * step;
@@ -252,7 +258,7 @@ int choose_stripe_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n, int64_t n
   int bestK = 0;
   for (int K : {1, 2, 4, 8}) {
     if (R > 0 && R % (64 * K) != 0) continue;
-    if (ctx->force_K && K != ctx->force_K) continue;
+    if (forced_K(ctx) && K != forced_K(ctx)) continue;
     const double step = (cell * K + step0) * 4.0;
     const double S = std::ceil((double)m / (64.0 * K));
     const double hops = n > 0 ? std::max(0.0, std::round((double)n_total / (double)n) - 1.0) : 0.0;
@@ -315,9 +321,11 @@ void launch_persistent(int K, dim3 grid, size_t lds, hipStream_t st, const FillA
         case 2: hipLaunchKernelGGL((fill_persistent<KIND, 2, F>), grid, blk, lds, st, a); break;
         case 4: hipLaunchKernelGGL((fill_persistent<KIND, 4, F>), grid, blk, lds, st, a); break;
         case 8: hipLaunchKernelGGL((fill_persistent<KIND, 8, F>), grid, blk, lds, st, a); break;
+        case 16: hipLaunchKernelGGL((fill_persistent<KIND, 16, F>), grid, blk, lds, st, a); break;
         case -1: hipLaunchKernelGGL((fill_persistent<KIND, 1, FN>), grid, blk, lds, st, a); break;
         case -2: hipLaunchKernelGGL((fill_persistent<KIND, 2, FN>), grid, blk, lds, st, a); break;
         case -4: hipLaunchKernelGGL((fill_persistent<KIND, 4, FN>), grid, blk, lds, st, a); break;
+        case -16: hipLaunchKernelGGL((fill_persistent<KIND, 16, FN>), grid, blk, lds, st, a); break;
         default: hipLaunchKernelGGL((fill_persistent<KIND, 8, FN>), grid, blk, lds, st, a); break;
       }
       return;
@@ -348,6 +356,7 @@ void launch_profile(int K, hipStream_t st, const uint8_t* xidx, int m, const int
     case 1: hipLaunchKernelGGL(build_profile<1>, dim3(blocks), dim3(256), 0, st, xidx, m, sub, alpha, S, prof); break;
     case 2: hipLaunchKernelGGL(build_profile<2>, dim3(blocks), dim3(256), 0, st, xidx, m, sub, alpha, S, prof); break;
     case 4: hipLaunchKernelGGL(build_profile<4>, dim3(blocks), dim3(256), 0, st, xidx, m, sub, alpha, S, prof); break;
+    case 16: hipLaunchKernelGGL(build_profile<16>, dim3(blocks), dim3(256), 0, st, xidx, m, sub, alpha, S, prof); break;
     default: hipLaunchKernelGGL(build_profile<8>, dim3(blocks), dim3(256), 0, st, xidx, m, sub, alpha, S, prof); break;
   }
 }
@@ -488,7 +497,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
     tun.K = choose_stripe_K(ctx, kind, m, n, sd->n_total, ev_out ? R : 0, lprof);
     tun.C = 64;
   } else if (persist) {
-    tun.K = choose_persist_K(ctx, kind, m, n, lprof);
+    tun.K = choose_persist_K(ctx, kind, m, n, lprof, /*has16=*/lprof && alpha <= 16);  // 16 rows per lane: profile within 64 KB of LDS
     tun.C = 64;
   }
   const int K = tun.K, C = tun.C;
@@ -1819,7 +1828,7 @@ int sa_set_stream(sa_ctx* c, void* s) {
 
 int sa_set_tuning(sa_ctx* c, int K, int C) {
   if (!c) return SA_ERR_ARG;
-  if (!(K == 0 || K == 1 || K == 2 || K == 4 || K == 8)) return fail(c, SA_ERR_ARG, "rows_per_lane must be 0,1,2,4,8");
+  if (!(K == 0 || K == 1 || K == 2 || K == 4 || K == 8 || K == 16)) return fail(c, SA_ERR_ARG, "rows_per_lane must be 0,1,2,4,8 (or 16: LCS only)");
   if (C < 0 || C % 64 != 0 || C > 4096) return fail(c, SA_ERR_ARG, "tile_steps must be a multiple of 64 (<=4096)");
   c->force_K = K;
   c->force_C = C;

@@ -128,3 +128,40 @@ def test_lcs_large_alphabet_keeps_the_compare_kernel(engine, oracle):
         y = np.concatenate([x[200:900], syms[rng.integers(0, nsym, 400)], x[1000:1400]])
         g, o = engine.lcs(x, y), oracle.lcs(x, y)
         assert g.score == o.score and np.array_equal(g.ops, o.ops), nsym
+
+
+def test_lcs_sixteen_rows_per_lane(pengine, oracle):
+    """The profile-driven LCS has a 16-rows-per-lane instance (1024-row strips: 1 Mb of rows is one round of waves).
+    Forced here on ragged shapes, tie storms and a many-strip pair; NW / SW and the byte-compare LCS take 8 instead."""
+    from sequencealigner_amd.synth import dna_pair
+
+    rng = np.random.default_rng(1600)
+    pengine.set_tuning(16, 0)
+    try:
+        for (m, n) in SHAPES + [(1023, 1025), (1024, 64), (1025, 3000), (5000, 3000), (300, 9000), (2049, 1)]:
+            g = check("lcs", pengine, oracle, rand_seq(rng, m, DNA), rand_seq(rng, n, DNA), "dna")
+            assert g.n_launches == 1 and (g.rows_per_lane == 16 or m == 0 or n == 0), (m, n, g.rows_per_lane)
+        for x, y in [("A" * 3000, "A" * 2570), ("AC" * 2000, "CA" * 1800), ("GATTACA" * 640, "GATACA" * 700)]:
+            check("lcs", pengine, oracle, x, y, "dna")
+        x = rand_seq(rng, 2500, PROT24)
+        check("lcs", pengine, oracle, x, mutate(rng, x, PROT20, 0.2, 0.05, 0.05), "protein")
+        x, y = dna_pair(40000, seed=11)
+        o, g = oracle.lcs(x, y, packed=True), pengine.lcs(x, y)
+        assert g.rows_per_lane == 16 and g.score == o.score and np.array_equal(g.ops, o.ops)
+        # checkpointed traceback over 1024-row strips
+        pengine.set_option("checkpoint_band", 2)
+        x = rand_seq(rng, 5000, DNA)
+        y = mutate(rng, x, DNA)
+        o, g = oracle.lcs(x, y), pengine.lcs(x, y)
+        assert g.score == o.score and np.array_equal(g.ops, o.ops) and g.n_launches >= 2
+        pengine.set_option("checkpoint_band", 0)
+        # no 16-row instances for NW / SW / more than 31 distinct bytes: 8 rows per lane then, same results
+        g = check("nw", pengine, oracle, rand_seq(rng, 3000, DNA), rand_seq(rng, 2000, DNA), "dna")
+        assert g.rows_per_lane == 8
+        syms = rng.permutation(256)[:200].astype(np.uint8)
+        xb, yb = syms[rng.integers(0, 200, 3000)], syms[rng.integers(0, 200, 2500)]
+        g, o = pengine.lcs(xb, yb), oracle.lcs(xb, yb)
+        assert g.rows_per_lane == 8 and g.score == o.score and np.array_equal(g.ops, o.ops)
+    finally:
+        pengine.set_option("checkpoint_band", 0)
+        pengine.set_tuning(0, 0)
