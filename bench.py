@@ -510,6 +510,21 @@ def main():
                 },
             },
         }
+        if args.kind == "lcs" and res.rows_per_lane == 32 and world == 1:
+            # bit-vector LCS (sa_lcsbits.hip): 3 integer operations per 32 cells, one bit of traceback record per cell;
+            # what it moves is the record, S x steps x 256 bytes per launch (m n / 8 + padding)
+            strips, steps_per_strip = (m + 2047) // 2048, ((n + 126 + 63) // 64) * 64
+            rec_bytes = strips * steps_per_strip * 256 * (1 if cells_trace else 0)
+            gbs = rec_bytes * args.steps / k_s / 1e9
+            line["roofline"] = {
+                "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                "traffic": None, "kernel": "lcs_bits_persistent", "bytes_per_cell": 0.125, "bytes_per_launch": rec_bytes,
+                "avg_launch_us": round(kernel_ms * 1e3 / max(launches, 1), 2),
+                "ns_per_column_step": round(kernel_ms * 1e6 / max(launches, 1) / steps_per_strip, 1),
+                "note": "the only HBM traffic of any size is the write-once traceback record (1 bit per cell).  The kernel does not reach the "
+                        "HBM roof: a strip is ONE wave sweeping n columns in sequence, about 11 instructions per column step, and a lone wave "
+                        "issues one instruction per 4+ cycles (DESIGN 3.1b); strips beyond the first add only the pipeline lag.",
+            }
         if schedule_note:
             line["config"]["schedule_note"] = schedule_note
         if not args.no_cpu and world == 1:

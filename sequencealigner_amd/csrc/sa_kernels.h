@@ -537,6 +537,8 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_tile(const FillArgs 
   }
 }
 
+// (The kernels that are not templates have internal linkage: this header is included by seqalign_hip.hip and by
+// sa_lcsbits.hip.)
 // ---- persistent strip pipeline ---------------------------------------------------------------
 // One launch for the whole fill.  A wave draws strips from a ticket counter in ascending order and
 // sweeps each one in sub-blocks of 16 steps.  Lane 0 of strip s consumes, at its step t, the bottom-row
@@ -753,7 +755,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
 }
 
 // host-initialised records of matrix row 0 (slot 0, generation 0): H[0][c+1] at index c + 64
-__global__ void init_row0_records(int2* __restrict__ dst, const int* __restrict__ h4, int n, int hconst, int f) {
+static __global__ void init_row0_records(int2* __restrict__ dst, const int* __restrict__ h4, int n, int hconst, int f) {
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
     const int h = h4 ? h4[c] : hconst;
     dst[64 + c] = make_int2(h & 0x3fffffff, f);
@@ -765,10 +767,10 @@ __global__ void init_row0_records(int2* __restrict__ dst, const int* __restrict_
 // stripe_signal follows the receive of chunk k in stream order and raises rows_in;
 // stripe_wait precedes the send of chunk k and returns once all strips of the chunk have counted
 // themselves into chunk_done[k] (bounded; raises *err when it gives up).
-__global__ void stripe_signal(int* rows_in, int rows) {
+static __global__ void stripe_signal(int* rows_in, int rows) {
   if (threadIdx.x == 0) st_coherent(rows_in, rows);
 }
-__global__ void stripe_wait(const int* cnt, int target, int* err, int spin_limit) {
+static __global__ void stripe_wait(const int* cnt, int target, int* err, int spin_limit) {
   if (threadIdx.x != 0) return;
   int spins = 0;
   while (ld_coherent(cnt) < target) {
@@ -809,13 +811,13 @@ __global__ void build_profile(const uint8_t* __restrict__ xidx, int m, const int
 }
 
 // ---- SW: reduce per-row bests to the first row-major maximum (main.cpp:1124-1127) ----
-__global__ void sw_reduce_max(const int* __restrict__ rowbest, int m, int* __restrict__ best) {
+static __global__ void sw_reduce_max(const int* __restrict__ rowbest, int m, int* __restrict__ best) {
   int v = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) v = max(v, rowbest[i]);
   for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
   if ((threadIdx.x & 63) == 0 && v > 0) atomicMax(best, v);
 }
-__global__ void sw_reduce_pos(const int* __restrict__ rowbest, const int* __restrict__ rowbestc, int m,
+static __global__ void sw_reduce_pos(const int* __restrict__ rowbest, const int* __restrict__ rowbestc, int m,
                               const int* __restrict__ best, unsigned long long* __restrict__ pos) {
   const int b = *best;
   if (b <= 0) return;
@@ -832,6 +834,10 @@ struct TraceArgs {
                           // walk stops when it reaches row i_min (with j > 0) and hands (i, j) over
   long long nops0;        // moves already written to `ops` by the walks over the bands below
   const uint32_t* trace;
+  // bit-vector LCS (sa_lcsbits.hip): `trace` holds one dword per (strip, step, lane) = 32 rows of one column of vertical
+  // differences, W = steps per strip; xs / ys are the symbols per row / column (a diagonal move is xs == ys)
+  const uint8_t* xs;
+  const uint8_t* ys;
   const int* sw_best;                  // SW: best score (device)
   const unsigned long long* sw_pos;    // SW: (i<<32)|j of the end cell (device)
   unsigned long long* ops2;            // out: the moves, two bits each, 32 to a word (expand_ops makes bytes of them)
@@ -1040,12 +1046,126 @@ __device__ __forceinline__ uint32_t walk_rounds(const bool tagged, const uint32_
   return c;
 }
 
+// Lane q of (lo, hi) <- the 64-lane mask "a == b".  One asm statement, because gfx950 wants two wait states between
+// a VALU instruction that writes a scalar register (the compare) and a VALU instruction that reads it as an operand
+// (v_writelane): the compiler inserts them in its own code but does not look inside inline assembly -- as two
+// statements the first v_writelane could see the PREVIOUS compare's mask, depending on what got scheduled between.
+__device__ __forceinline__ void ballot_eq_to_lane(uint32_t& lo, uint32_t& hi, uint32_t a, uint32_t b, const int q) {
+  asm("v_cmp_eq_u32_e64 vcc, %2, %3\n\t"
+      "s_nop 1\n\t"
+      "v_writelane_b32 %0, vcc_lo, %4\n\t"
+      "v_writelane_b32 %1, vcc_hi, %4"
+      : "+v"(lo), "+v"(hi)
+      : "v"(a), "v"(b), "n"(q)
+      : "vcc");
+}
+
+// ---- bit-vector LCS (sa_lcsbits.hip): the same walker over one bit per cell ----
+// The fill stores, per column, the vertical differences of the L matrix as bit vectors: bit (r & 31) of dword
+// [strip][step c + kBitsSkew * lane][lane] (row r 0-based in word g = r >> 5 = strip * 64 + lane, column c 0-based) is CLEAR iff
+// L[r+1][c+1] = L[r][c+1] + 1.  The reference's pointer at a cell (main.cpp:1577-1587) follows from it: diagonal iff
+// the symbols match, else up iff L[i-1][j] >= L[i][j-1], which in a mismatch cell (L[i][j] = max of the two) is
+// "the vertical difference is 0", i.e. the bit is SET; else left.
+constexpr int kBitsSkew = 2;  // the fill's skew (sa_lcsbits.hip): lane l meets column c at step c + kBitsSkew * l
+__device__ __forceinline__ uint32_t bits_word(const TraceArgs& a, int g, int c) {
+  const int sidx = g >> 6, l = g & 63;
+  return a.trace[((size_t)sidx * a.W + (c + kBitsSkew * l)) * 64 + l];
+}
+// op code (0 diagonal, 1 left, 2 up) of cell (i, j), 1-based
+__device__ __forceinline__ uint32_t bits_code(const TraceArgs& a, int i, int j) {
+  const int r = i - 1, c = j - 1;
+  if (a.xs[r] == a.ys[c]) return 0u;
+  return ((bits_word(a, r >> 5, c) >> (r & 31)) & 1u) ? 2u : 1u;
+}
+// The 64-row window of the walker, by COLUMNS: lane q keeps rows i-63 .. i of column j0 - 79 + q (a0..a2, three dwords
+// because the rows need not start on a word) and of column j0 - 15 + q (b0..b2; 31 of them are used), the symbol of
+// both columns, and the symbol of row i - q.  96 columns = the 64 the diagonal through the entry cell crosses + 16 of
+// drift on both sides, ~200 sectors per window (the 2-bit codes of the other kernels take about as many).
+struct BitsWindow {
+  uint32_t a0, a1, a2, b0, b1, b2;
+  uint32_t ya, yb, xv;
+};
+__device__ __forceinline__ BitsWindow load_bits_window(const TraceArgs& a, int i, int j0, int q) {
+  const int g0 = (i - 64) >> 5;
+  const int glast = ((a.m + 2047) / 2048) * 64 - 1;
+  const int g1 = g0 + 1, g2 = min(g0 + 2, glast);
+  const int cA = j0 - 80 + q, cB = min(j0 - 16 + q, a.n - 1);
+  BitsWindow w;
+  w.a0 = bits_word(a, g0, cA);
+  w.a1 = bits_word(a, g1, cA);
+  w.a2 = bits_word(a, g2, cA);
+  w.b0 = bits_word(a, g0, cB);
+  w.b1 = bits_word(a, g1, cB);
+  w.b2 = bits_word(a, g2, cB);
+  w.ya = a.ys[cA];
+  w.yb = a.ys[cB];
+  w.xv = a.xs[i - 1 - q];
+  return w;
+}
+// walk_rounds for the bit-vector window.  dm as there (lane q: the 64-row mask "drift q - 16 is a match"); ca / cb:
+// lane q holds the 64 row bits (bit d = row i - d) of column j0 - 79 + q / j0 - 15 + q.  The gap move at (d, o) sits in
+// column j0 - d + o = lane 79 - d + o of ca, or of cb when that is 64 or more (v_readlane takes the lane modulo 64).
+__device__ __forceinline__ void walk_rounds_bits(const uint32_t dm_lo, const uint32_t dm_hi, const uint32_t ca_lo, const uint32_t ca_hi,
+                                                 const uint32_t cb_lo, const uint32_t cb_hi, int& dcur, int& o, int& k,
+                                                 unsigned long long& acc) {
+  uint32_t t0, t1, L;
+  asm volatile(
+      "Ltop_%=:\n\t"
+      "s_add_i32 %[t0], %[o], 16\n\t"
+      "v_readlane_b32 vcc_hi, %[dmhi], %[t0]\n\t"
+      "v_readlane_b32 vcc_lo, %[dmlo], %[t0]\n\t"
+      "s_lshr_b64 vcc, vcc, %[d]\n\t"
+      "s_not_b64 vcc, vcc\n\t"
+      "s_ff1_i32_b64 %[L], vcc\n\t"
+      "s_sub_i32 %[t1], 64, %[d]\n\t"
+      "s_min_u32 %[L], %[L], %[t1]\n\t"
+      "s_add_i32 %[k], %[k], %[L]\n\t"
+      "s_add_i32 %[d], %[d], %[L]\n\t"
+      "s_cmp_ge_i32 %[k], 32\n\t"
+      "s_cbranch_scc1 Lout_%=\n\t"
+      "s_cmp_ge_i32 %[d], 64\n\t"
+      "s_cbranch_scc1 Lout_%=\n\t"
+      "s_sub_i32 %[t0], 79, %[d]\n\t"
+      "s_add_i32 %[t0], %[t0], %[o]\n\t"
+      "v_readlane_b32 vcc_hi, %[cahi], %[t0]\n\t"
+      "v_readlane_b32 vcc_lo, %[calo], %[t0]\n\t"
+      "v_readlane_b32 %[t1], %[cblo], %[t0]\n\t"
+      "v_readlane_b32 %[L], %[cbhi], %[t0]\n\t"
+      "s_cmp_lt_u32 %[t0], 64\n\t"
+      "s_cselect_b32 vcc_lo, vcc_lo, %[t1]\n\t"
+      "s_cselect_b32 vcc_hi, vcc_hi, %[L]\n\t"
+      "s_lshr_b64 vcc, vcc, %[d]\n\t"
+      "s_and_b32 %[t1], vcc_lo, 1\n\t"
+      "s_add_i32 %[t1], %[t1], 1\n\t"          // op: 1 left (bit clear), 2 up (bit set)
+      "s_lshl_b32 %[t0], %[k], 1\n\t"
+      "s_mov_b32 vcc_hi, 0\n\t"
+      "s_mov_b32 vcc_lo, %[t1]\n\t"
+      "s_lshl_b64 vcc, vcc, %[t0]\n\t"
+      "s_or_b64 %[acc], %[acc], vcc\n\t"
+      "s_add_i32 %[k], %[k], 1\n\t"
+      "s_lshr_b32 %[t1], %[t1], 1\n\t"
+      "s_add_i32 %[d], %[d], %[t1]\n\t"
+      "s_lshl_b32 %[t1], %[t1], 1\n\t"
+      "s_add_i32 %[o], %[o], %[t1]\n\t"
+      "s_add_i32 %[o], %[o], -1\n\t"
+      "s_add_i32 %[t0], %[o], 16\n\t"
+      "s_cmp_lt_u32 %[t0], 32\n\t"
+      "s_cbranch_scc1 Ltop_%=\n\t"
+      "Lout_%=:\n\t"
+      : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L)
+      : [dmlo] "v"(dm_lo), [dmhi] "v"(dm_hi), [calo] "v"(ca_lo), [cahi] "v"(ca_hi), [cblo] "v"(cb_lo), [cbhi] "v"(cb_hi)
+      : "scc", "vcc");
+}
+
+// BITS: the bit-vector LCS format above instead of 2-bit codes (whole matrix only: no bands, no stripes)
+template <bool BITS>
 __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
   // The packed moves are staged in LDS and written out in bulk: with no global stores inside the walk, the
   // only vector-memory operations in flight are the loads of the NEXT window, so waiting for them
   // at the top of the next round (vmcnt counts loads and stores together, in order) waits for
   // nothing else -- the prefetch really overlaps the walk through the current window.
   __shared__ unsigned long long stage[kTraceStageWords];
+  __shared__ uint8_t ywin[BITS ? 128 : 8];  // BITS: the target symbols of the window's 96 columns
   const int d = threadIdx.x;
   const bool tagged = a.kind != KIND_LCS;
   int lgK = 0;
@@ -1087,7 +1207,14 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
   const uint32_t rawD = tagged ? 2u : 3u;
   bool have = false;  // nw holds the window of entry cell (pi, pj)
   int pi = 0, pj = 0;
-  TraceWindow nw{0, 0, 0, 0};
+  using Window = std::conditional_t<BITS, BitsWindow, TraceWindow>;
+  Window nw{};
+  auto load_window = [&](int wi, int wj) {
+    if constexpr (BITS)
+      return load_bits_window(a, wi, wj, d);
+    else
+      return load_trace_window(a.trace, wi - i_min, wj, d, lgK, a.W);
+  };
   bool stopped = false;
   while (i > i_min && j > 0 && !stopped) {
     if (em.staged > kTraceStageWords - 16) em.flush();  // a window adds at most 4 words
@@ -1098,10 +1225,10 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
         pi = i;
         pj = j;
         have = true;
-        nw = load_trace_window(a.trace, pi - i_min, pj, d, lgK, a.W);
+        nw = load_window(pi, pj);
         continue;
       }
-      const TraceWindow w = nw;
+      const Window w = nw;
       const int j0 = pj;
       int o = j - pj;
       // prefetch along the diagonal; a path that drifts more than 14 columns in 64 rows misses it
@@ -1109,26 +1236,47 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
       if (have) {
         pi = i - 64;
         pj = j - 64;
-        nw = load_trace_window(a.trace, pi - i_min, pj, d, lgK, a.W);
+        nw = load_window(pi, pj);
       }
       const int o_in = o;
+      uint32_t dm_lo = 0, dm_hi = 0;
+      uint32_t Flo = 0, Fhi = 0, ca_lo = 0, ca_hi = 0, cb_lo = 0, cb_hi = 0;
+      if constexpr (BITS) {
+        // rows i-64 .. i-1 (0-based) start at bit sh of the three dwords; reversed, so that bit d is row i - d
+        const int sh = (i - 64) & 31;
+        ca_lo = __builtin_bitreverse32(__builtin_amdgcn_alignbit(w.a2, w.a1, sh));
+        ca_hi = __builtin_bitreverse32(__builtin_amdgcn_alignbit(w.a1, w.a0, sh));
+        cb_lo = __builtin_bitreverse32(__builtin_amdgcn_alignbit(w.b2, w.b1, sh));
+        cb_hi = __builtin_bitreverse32(__builtin_amdgcn_alignbit(w.b1, w.b0, sh));
+        // diagmask from the symbols: row i - d meets, at drift o, column j0 - d + o = entry 79 - d + o of the window
+        wave_lds_fence();  // the previous window's reads are done
+        ywin[d] = (uint8_t)w.ya;
+        ywin[64 + d] = (uint8_t)w.yb;
+        wave_lds_fence();
+#pragma unroll
+        for (int q = 0; q < 32; ++q) ballot_eq_to_lane(dm_lo, dm_hi, (uint32_t)ywin[63 - d + q], w.xv, q);
+      } else {
       // The lane's 32 codes around its own cell of the entry diagonal, as one 64-bit value: the code
       // at drift o (-16..15) is bits [2(o+16), 2(o+16)+1] (two funnel shifts per window).
       const int sh0 = 2 * (w.pb - 16);
-      const uint32_t Flo = __builtin_amdgcn_alignbit(w.w1, w.w0, sh0), Fhi = __builtin_amdgcn_alignbit(w.w2, w.w1, sh0);
+      Flo = __builtin_amdgcn_alignbit(w.w1, w.w0, sh0), Fhi = __builtin_amdgcn_alignbit(w.w2, w.w1, sh0);
       // Walk the window on the scalar unit.  diagmask[q] (lane q of dm_lo / dm_hi, q = drift + 16) says for which of
       // the 64 rows the cell at that drift is a diagonal move: one ballot per drift, 32 per window, all lanes at
       // once.  Then every round of the loop below is "the diagonal run from here (a shift and a find-first-zero on
       // that mask, possibly empty), then ONE gap move (the row's codes sit in two scalar registers: a shift, an
       // OR into the emitter)" -- no vector work and no memory access per move, one round per gap move.
-      uint32_t dm_lo = 0, dm_hi = 0;
 #pragma unroll
       for (int q = 0; q < 32; ++q) {
         const uint32_t cq = ((q < 16 ? Flo : Fhi) >> (2 * (q & 15))) & 3u;
-        const unsigned long long bq = __ballot(cq == rawD);
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(dm_lo) : "s"((uint32_t)bq), "n"(q));
-        asm("v_writelane_b32 %0, %1, %2" : "+v"(dm_hi) : "s"((uint32_t)(bq >> 32)), "n"(q));
+        ballot_eq_to_lane(dm_lo, dm_hi, cq, rawD, q);
       }
+      }
+#ifdef SA_DEBUG_BITS
+      if constexpr (BITS) {
+        printf("W i=%d j0=%d o=%d lane=%d xv=%u ya=%u yb=%u a=%08x %08x %08x b=%08x %08x %08x dm=%08x%08x ca=%08x%08x cb=%08x%08x\n", i, j0, o, d, w.xv, w.ya,
+               w.yb, w.a0, w.a1, w.a2, w.b0, w.b1, w.b2, dm_hi, dm_lo, ca_hi, ca_lo, cb_hi, cb_lo);
+      }
+#endif
       int dcur = 0;
       unsigned long long acc = em.acc;  // the emitter's state in scalars of our own for the duration of the window
       int k = em.k, staged = em.staged;
@@ -1136,7 +1284,11 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
         // One round = the diagonal run from (dcur, o), then one gap move; rounds follow each other inside the
         // assembly until something rare happens (see walk_rounds).  Written by hand because the compiled loop
         // took four taken branches per round, and a lone wave pays ~50 cycles of instruction fetch for each.
-        const uint32_t c = walk_rounds(tagged, dm_lo, dm_hi, Flo, Fhi, dcur, o, k, acc);
+        uint32_t c = 0;
+        if constexpr (BITS)
+          walk_rounds_bits(dm_lo, dm_hi, ca_lo, ca_hi, cb_lo, cb_hi, dcur, o, k, acc);
+        else
+          c = walk_rounds(tagged, dm_lo, dm_hi, Flo, Fhi, dcur, o, k, acc);
         while (k >= 32) {  // all lanes store the same word to the same place: no divergence
           stage[staged++] = acc;
           acc = 0;
@@ -1162,9 +1314,16 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
     const bool vM = (i - d > i_min) && (j - d >= 1);
     const bool vE = (j - d >= 1);
     const bool vF = (i - d > i_min);
-    const uint32_t cM = vM ? trace_code(a.trace, i - d - i_min, j - d, lgK, a.W, tagged) : 3u;
-    const uint32_t cE = vE ? trace_code(a.trace, i - i_min, j - d, lgK, a.W, tagged) : 3u;
-    const uint32_t cF = vF ? trace_code(a.trace, i - d - i_min, j, lgK, a.W, tagged) : 3u;
+    uint32_t cM = 3u, cE = 3u, cF = 3u;
+    if constexpr (BITS) {
+      if (vM) cM = bits_code(a, i - d, j - d);
+      if (vE) cE = bits_code(a, i, j - d);
+      if (vF) cF = bits_code(a, i - d, j);
+    } else {
+      if (vM) cM = trace_code(a.trace, i - d - i_min, j - d, lgK, a.W, tagged);
+      if (vE) cE = trace_code(a.trace, i - i_min, j - d, lgK, a.W, tagged);
+      if (vF) cF = trace_code(a.trace, i - d - i_min, j, lgK, a.W, tagged);
+    }
     const uint32_t c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)cM);
     if (c0 == 3u) break;  // SW stop cell ('X', main.cpp:1233)
     unsigned long long run;
@@ -1212,7 +1371,7 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
 }
 
 // packed moves -> one byte per move (the C-ABI's op list); hdr[0] = number of moves
-__global__ void expand_ops(const unsigned long long* __restrict__ ops2, uint8_t* __restrict__ ops, const long long* __restrict__ hdr) {
+static __global__ void expand_ops(const unsigned long long* __restrict__ ops2, uint8_t* __restrict__ ops, const long long* __restrict__ hdr) {
   const long long n = hdr[0];
   for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (long long)gridDim.x * blockDim.x)
     ops[q] = (uint8_t)((ops2[q >> 5] >> (2 * (q & 31))) & 3ull);

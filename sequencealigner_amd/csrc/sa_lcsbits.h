@@ -1,0 +1,24 @@
+// sa_lcsbits.h -- launch interface of the bit-vector LCS kernels (sa_lcsbits.hip), used by seqalign_hip.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "sa_kernels.h"
+
+namespace sa {
+
+constexpr int kBitsRowsPerLane = 32;                      // one dword of vertical differences per lane
+constexpr int kBitsStripRows = 64 * kBitsRowsPerLane;     // 2048 rows per strip (wavefront)
+constexpr int kBitsRecord0 = 256;                         // index of column 0 in a slot of hand-off records
+constexpr int kBitsMaxAlpha = 64;                         // profile symbols incl. the padding symbol: 16 KB of LDS per wave
+
+// prof[s][sym][lane] = the rows (bit b = row (s * 64 + lane) * 32 + b) whose symbol is `sym`
+void bits_launch_profile(hipStream_t st, const uint8_t* xs, int m, int alpha, int S, uint32_t* prof);
+// steps per strip (a multiple of 64) and record-slot length for n columns
+int bits_steps(int n);
+int bits_slot_len(int n);
+// the fill: FillArgs as for fill_persistent (W = steps per strip, trace = [S][W][64] dwords or null: score only)
+void bits_launch_fill(hipStream_t st, int grid_blocks, const FillArgs& a);
+// the walker over that format (TraceArgs::xs / ys / W set)
+void bits_launch_traceback(hipStream_t st, const TraceArgs& t);
+
+}  // namespace sa

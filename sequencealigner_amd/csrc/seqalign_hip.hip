@@ -19,6 +19,7 @@
 #include "../../include/seqalign_hip.h"
 #include "sa_batch.h"
 #include "sa_kernels.h"
+#include "sa_lcsbits.h"
 #include "sa_tables.h"
 
 using namespace sa;
@@ -67,6 +68,7 @@ struct sa_ctx {
   int force_K = 0, force_C = 0;
   size_t batch_trace_budget = (size_t)32 << 30;  // sa_sw_batch_align: device bytes of direction codes per chunk
   int persist = 1;  // 1: persistent strip pipeline (one launch) where it applies
+  int lcs_bits = 1; // 1: LCS of a whole pair over at most 63 distinct bytes runs as bit-vector arithmetic (sa_lcsbits.hip)
   int wps = 1;      // persistent kernel: waves per SIMD to launch
   int n_cu = 256;
   // cached device workspaces
@@ -83,6 +85,7 @@ struct sa_ctx {
     // checkpointed fill: the codes did not fit, only every strip's bottom row was kept; the
     // traceback recomputes `band` strips at a time from these arguments
     int ckpt = 0, band = 0, S = 0, lprof = 0;
+    int bits = 0;  // the codes are the bit vectors of sa_lcsbits.hip (W = steps per strip)
     sa::FillArgs args;
     size_t lds = 0;
   } last;
@@ -822,8 +825,121 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   ctx->last.args = a;
   ctx->last.lds = lds;
   ctx->last.lprof = lprof;
+  ctx->last.bits = 0;
   // cells this fill computed, by the work done per cell (with / without direction codes)
   (a.trace ? out->cells_trace : out->cells_notrace) = (int64_t)m * n;
+  return SA_OK;
+}
+
+// LCS of one whole pair as bit-vector arithmetic (sa_lcsbits.hip): 32 rows per lane and one bit of traceback record
+// per cell.  Applies when the pair holds at most 63 distinct bytes (DNA, proteins, text), the record (m n / 8 bytes)
+// fits the budget, and nothing asks for the cell-by-cell kernels (matrix dump, forced rows per lane, forced
+// checkpointing, column stripes).  *used = false: the caller takes fill_impl instead.  Events as in fill_impl.
+int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n, uint32_t flags, sa_result* out, bool* used) {
+  *used = false;
+  if (!ctx->lcs_bits || !ctx->persist || ctx->force_K || ctx->force_band > 0 || (flags & SA_FLAG_KEEP_DP)) return SA_OK;
+  uint8_t lmap[256];
+  bool seen[256] = {false};
+  for (int i = 0; i < m; ++i) seen[x[i]] = true;
+  for (int j = 0; j < n; ++j) seen[y[j]] = true;
+  int A = 0;
+  for (int b = 0; b < 256; ++b)
+    if (seen[b]) lmap[b] = (uint8_t)std::min(A++, 255);
+  if (A + 1 > kBitsMaxAlpha) return SA_OK;
+  const int alpha = A + 1;  // + the padding symbol (empty masks)
+  HIPCK(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = ctx->stream;
+  const int S = (m + kBitsStripRows - 1) / kBitsStripRows;
+  const int Tend = bits_steps(n);
+  const int NP = bits_slot_len(n);
+  const bool no_tb = (flags & SA_FLAG_NO_TRACEBACK) != 0;
+  const size_t trace_bytes = no_tb ? 0 : (size_t)S * Tend * 64 * 4;
+  size_t budget = ctx->trace_budget;
+  if (!budget) {
+    size_t free_b = 0, total_b = 0;
+    HIPCK(ctx, hipMemGetInfo(&free_b, &total_b));
+    budget = (size_t)((double)total_b * 0.88);
+  }
+  if (trace_bytes > budget) return SA_OK;
+  const int grid_blocks = std::min((S + kWavesPerBlock - 1) / kWavesPerBlock, ctx->n_cu * std::max(1, ctx->wps));
+  const int ring = std::min(S + 1, grid_blocks * kWavesPerBlock + 2);
+  const size_t rows_pad = (size_t)S * kBitsStripRows;
+  int rc;
+  {
+    const size_t need_bot = (size_t)2 * ring * NP * 4;
+    if (need_bot > ctx->bot.cap || trace_bytes > ctx->trace.cap) {
+      release(ctx->bot);
+      release(ctx->trace);
+      release(ctx->dpbuf);
+    }
+  }
+  if ((rc = ensure(ctx, ctx->xenc, rows_pad + 64))) return rc;
+  if ((rc = ensure(ctx, ctx->yenc, (size_t)Tend + 256))) return rc;
+  if ((rc = ensure(ctx, ctx->bot, (size_t)2 * ring * NP * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->small, 256))) return rc;
+  if ((rc = ensure(ctx, ctx->pbuf, 256))) return rc;
+  if ((rc = ensure(ctx, ctx->ops, ops_bytes_offset(m, n) + ((size_t)m + n) / 4 + 1024))) return rc;
+  if ((rc = ensure(ctx, ctx->prof, (size_t)S * alpha * 64 * 4))) return rc;
+  if (trace_bytes && (rc = ensure(ctx, ctx->trace, trace_bytes))) return rc;
+  std::vector<uint8_t> xe(rows_pad + 64, 0), ye((size_t)Tend + 256, (uint8_t)(alpha - 1));
+  for (int i = 0; i < m; ++i) xe[i] = lmap[x[i]];
+  for (int j = 0; j < n; ++j) ye[j] = lmap[y[j]];
+
+  HIPCK(ctx, hipEventRecord(ctx->ev[0], st));
+  HIPCK(ctx, hipMemcpyAsync(ctx->xenc.p, xe.data(), xe.size(), hipMemcpyHostToDevice, st));
+  HIPCK(ctx, hipMemcpyAsync(ctx->yenc.p, ye.data(), ye.size(), hipMemcpyHostToDevice, st));
+  int2* bot2 = (int2*)ctx->bot.p;
+  // records: generation 3 = "not yet written"; the carries into matrix row 1 are zero ("strip -1", slot 0, generation 0)
+  HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)bot2, (int)0xC0000000u, (size_t)2 * ring * NP, st));
+  // (init_row0_records writes column c at index c + 64)
+  hipLaunchKernelGGL(init_row0_records, dim3(std::min((n + 255) / 256, 2048)), dim3(256), 0, st, bot2 + (kBitsRecord0 - 64), (const int*)nullptr, n, 0, 0);
+  HIPCK(ctx, hipMemsetAsync(ctx->small.p, 0, 256, st));
+  HIPCK(ctx, hipMemsetAsync(ctx->pbuf.p, 0, 256, st));
+  bits_launch_profile(st, (const uint8_t*)ctx->xenc.p, m, alpha, S, (uint32_t*)ctx->prof.p);
+  FillArgs a{};
+  a.m = m;
+  a.n = n;
+  a.S = S;
+  a.C = 64;
+  a.W = Tend;
+  a.alpha = alpha;
+  a.NP = NP;
+  a.yenc = (const uint8_t*)ctx->yenc.p;
+  a.prof = (const uint32_t*)ctx->prof.p;
+  a.xpad = (const uint8_t*)ctx->xenc.p;
+  a.bot2 = bot2;
+  a.ring = ring;
+  a.trace = no_tb ? nullptr : (uint32_t*)ctx->trace.p;
+  a.trace_s0 = 0;
+  a.score_out = (int*)ctx->small.p;
+  a.ticket = (int*)ctx->pbuf.p;
+  a.s_first = 0;
+  a.s_last = S - 1;
+  a.err = (int*)ctx->small.p + 40;
+  a.spin_limit = 1 << 22;
+  HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
+  bits_launch_fill(st, grid_blocks, a);
+  HIPCK(ctx, hipGetLastError());
+  HIPCK(ctx, hipEventRecord(ctx->ev[2], st));
+  out->n_launches = 1;
+  out->rows_per_lane = kBitsRowsPerLane;
+  out->tile_steps = 64;
+  ctx->last.valid = 1;
+  ctx->last.kind = KIND_LCS;
+  ctx->last.m = m;
+  ctx->last.n = n;
+  ctx->last.K = kBitsRowsPerLane;
+  ctx->last.W = Tend;
+  ctx->last.first_stripe = 1;
+  ctx->last.ckpt = 0;
+  ctx->last.band = S;
+  ctx->last.S = S;
+  ctx->last.args = a;
+  ctx->last.lds = 0;
+  ctx->last.lprof = 0;
+  ctx->last.bits = 1;
+  (a.trace ? out->cells_trace : out->cells_notrace) = (int64_t)m * n;
+  *used = true;
   return SA_OK;
 }
 
@@ -892,7 +1008,7 @@ int traceback_ckpt(sa_ctx* ctx, int start_i, int start_j, sa_result* out) {
     t.sw_pos = (const unsigned long long*)((char*)ctx->small.p + 8);
     t.ops2 = (unsigned long long*)((char*)ctx->ops.p + ops_bytes_offset(m, n));
     t.hdr = d_hdr;
-    hipLaunchKernelGGL(traceback_walk, dim3(1), dim3(64), 0, st, t);
+    hipLaunchKernelGGL(traceback_walk<false>, dim3(1), dim3(64), 0, st, t);
     HIPCK(ctx, hipGetLastError());
     long long h_hdr[5] = {0, 0, 0, 0, 0};
     int h_err = 0;
@@ -954,7 +1070,13 @@ int traceback_impl(sa_ctx* ctx, int start_i, int start_j, bool want_tb, sa_resul
     t.sw_pos = d_pos;
     t.ops2 = (unsigned long long*)((char*)ctx->ops.p + ops_bytes_offset(m, n));
     t.hdr = d_hdr;
-    hipLaunchKernelGGL(traceback_walk, dim3(1), dim3(64), 0, st, t);
+    if (ctx->last.bits) {
+      t.xs = (const uint8_t*)ctx->xenc.p;
+      t.ys = (const uint8_t*)ctx->yenc.p;
+      bits_launch_traceback(st, t);
+    } else {
+      hipLaunchKernelGGL(traceback_walk<false>, dim3(1), dim3(64), 0, st, t);
+    }
     launch_expand_ops(ctx, m, n, (long long)m + n, d_hdr);
     HIPCK(ctx, hipGetLastError());
     HIPCK(ctx, hipMemcpyAsync(h_hdr, d_hdr, sizeof h_hdr, hipMemcpyDeviceToHost, st));
@@ -1042,7 +1164,9 @@ int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t
   if (m == 0 || n == 0) {
     border_only_result(kind, m, n, rowb, colb, out);
   } else {
-    if ((rc = fill_impl(ctx, kind, x, m, y, n, sc, nullptr, flags, out, rowb, colb))) return rc;
+    bool bits = false;
+    if (kind == KIND_LCS && (rc = lcs_bits_fill(ctx, x, m, y, n, flags, out, &bits))) return rc;
+    if (!bits && (rc = fill_impl(ctx, kind, x, m, y, n, sc, nullptr, flags, out, rowb, colb))) return rc;
     if (dump) HIPCK(ctx, hipMemcpyAsync(out->dp, ctx->dpbuf.p, ((size_t)m + 1) * ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = traceback_impl(ctx, -1, -1, !(flags & SA_FLAG_NO_TRACEBACK), out))) return rc;
     float t01 = 0, t12 = 0, t23 = 0;
@@ -1839,6 +1963,8 @@ int sa_set_option(sa_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return SA_ERR_ARG;
   if (!strcmp(name, "persistent")) {
     c->persist = value != 0;
+  } else if (!strcmp(name, "lcs_bits")) {  // 0: LCS always through the cell-by-cell kernels
+    c->lcs_bits = value != 0;
   } else if (!strcmp(name, "checkpoint_band")) {  // 0: checkpoint only when the codes do not fit
     if (value < 0) return fail(c, SA_ERR_ARG, "checkpoint_band must be >= 0");
     c->force_band = (int)value;
