@@ -258,6 +258,17 @@ def bench_batch(args, rank, local_rank, world, dist, torch, workload=None, neste
     return line
 
 
+def lcs_pmc_traffic(m, n):
+    """Measured HBM bytes per launch of the bit-vector LCS kernel, from the committed PMC summary (1 Mb pair only)."""
+    f = ROOT / "profiles" / "r02_lcs1m_pmc.json"
+    if not (f.exists() and m == 1_000_000):
+        return None
+    try:
+        return int(json.loads(f.read_text())["derived"]["hbm_traffic_bytes_per_launch"])
+    except (KeyError, ValueError):
+        return None
+
+
 def batch_pmc_traffic(workload, per_rank):
     """HBM bytes per call of the batch kernels from the committed PMC passes (profiles/r02_batch_pmc.json), scaled
     by the number of pairs (the traffic is per pair: sequences in, descriptors in, results out); null when there
@@ -518,7 +529,8 @@ def main():
             gbs = rec_bytes * args.steps / k_s / 1e9
             line["roofline"] = {
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                "traffic": None, "kernel": "lcs_bits_persistent", "bytes_per_cell": 0.125, "bytes_per_launch": rec_bytes,
+                "traffic": lcs_pmc_traffic(m, n), "kernel": "lcs_bits_persistent", "bytes_per_cell": 0.125, "bytes_per_launch": rec_bytes,
+                "traffic_note": "HBM bytes per launch, WRITE_SIZE + 2 x FETCH_SIZE of the PMC passes in profiles/r02_lcs1m_pmc.json (that workload only)",
                 "avg_launch_us": round(kernel_ms * 1e3 / max(launches, 1), 2),
                 "ns_per_column_step": round(kernel_ms * 1e6 / max(launches, 1) / steps_per_strip, 1),
                 "note": "the only HBM traffic of any size is the write-once traceback record (1 bit per cell).  The kernel does not reach the "

@@ -32,7 +32,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
   uint32_t* lds = lds_all + (threadIdx.x >> 6) * (a.alpha * 64);
   const int NB = a.W / 64;  // steps per strip: n + 2 * 63, rounded up to whole blocks
   const int ypad = (a.alpha - 1) * 256;  // LDS byte offset of the padding symbol's (empty) masks
-  constexpr int D = 2;                   // records are requested two sub-blocks ahead
+  constexpr int D = 4;                   // records are requested four sub-blocks ahead
 
   while (true) {
     int s = 0;
@@ -79,17 +79,37 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
 
     uint32_t V = 0xffffffffu;  // column 0 of L is all zeros: no vertical step anywhere
     // What travels down the lanes is not the symbol but the LDS address of its mask for the receiving lane: lane l
-    // takes the address lane l-1 used two steps ago, plus 4 (prof[sym][lane] is a dword per lane) -- one
+    // takes the address lane l-1 used kBitsSkew steps ago, plus 4 (prof[sym][lane] is a dword per lane) -- one
     // v_add_u32_dpp; lane 0 takes the next entry of the in-buffer yb (the block's 64 symbols, rotated once per step).
-    const int lds0 = (int)((threadIdx.x >> 6) * (a.alpha * 64) * 4);  // this wave's slice of the dynamic LDS, in bytes
+    // This stream of masks runs ONE SUB-BLOCK AHEAD of the arithmetic and its instructions sit between those of the
+    // carry chain (and -> add with carry -> bitop is a chain of dependent instructions; back to back each waits for
+    // the one before: 39 ns per step measured against 25 with independent work between them).
+    // (as absolute LDS addresses, so that the read is ds_read_b32 on the travelling value itself)
+    typedef __attribute__((address_space(3))) const uint32_t lds_u32;
+    const int lds0 = (int)(uintptr_t)(__attribute__((address_space(3))) uint32_t*)lds;  // this wave's slice of the dynamic LDS
     int adp[kBitsSkew];  // the addresses this lane used 1 .. kBitsSkew steps ago; before column 0: the padding symbol
 #pragma unroll
     for (int q = 0; q < kBitsSkew; ++q) adp[q] = lds0 + ypad + lane * 4;
     const int four = 4;
-    int ny = a.yenc[lane];
+    int yb = a.yenc[lane] * 256 + lds0;  // block 0
+    int ny = a.yenc[64 + lane];          // block 1
+    int nyn = 0;
+    uint32_t Mc[16], Mn[16];             // masks of the current / the next sub-block
+    auto lds_mask = [](int ad) { return *(lds_u32*)(uintptr_t)(uint32_t)ad; };
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {  // sub-block 0
+      const int nyb = dpp_shl1_any(yb);
+      int ad = yb;  // lane 0 keeps this (its source lane does not exist)
+      asm("v_add_u32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(ad) : "v"(adp[kBitsSkew - 1]), "v"(four));
+      yb = nyb;
+#pragma unroll
+      for (int q = kBitsSkew - 1; q > 0; --q) adp[q] = adp[q - 1];
+      adp[0] = ad;
+      Mc[u] = lds_mask(ad);
+    }
     uint32_t inb = 0;
     bool dead = !acquire(pend[0], 0, inb);
-    // carry-out masks of the last two steps (bit l = carry out of lane l): co2, shifted left by one, is due now
+    // carry-out masks of the last kBitsSkew steps (bit l = carry out of lane l): the oldest, shifted left by one, is due now
     unsigned long long cop[kBitsSkew];
 #pragma unroll
     for (int q = 0; q < kBitsSkew; ++q) cop[q] = 0;
@@ -98,10 +118,13 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
 #pragma unroll 1
     for (int b = 0; b < NB && !dead; ++b) {
       const int Tb = 64 * b;
-      int yb = ny * 256 + lds0;
       auto sub_block = [&](auto subc) -> bool {
         constexpr int sub = decltype(subc)::value;
         const int Ts = Tb + 16 * sub;
+        if (sub == 3) {  // the mask stream enters the next block
+          yb = ny * 256 + lds0;
+          ny = nyn;
+        }
         // wave-uniform by construction; said explicitly, because a value that crosses the block loop is otherwise
         // kept in vector registers and the carry operand of v_addc_co_u32 must be a scalar pair
 #pragma unroll
@@ -110,53 +133,50 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
                    (uint32_t)__builtin_amdgcn_readfirstlane((int)cop[q]);
         inb = (uint32_t)__builtin_amdgcn_readfirstlane((int)inb);
         unsigned long long cos[16];
-        // the 16 masks first (they do not depend on V): the LDS latency is paid once per sub-block
-        uint32_t Ms[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-          const int nyb = dpp_shl1_any(yb);
-          int ad = yb;  // lane 0 keeps this (its source lane does not exist)
-          asm("v_add_u32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(ad) : "v"(adp[kBitsSkew - 1]), "v"(four));
-          yb = nyb;
-#pragma unroll
-          for (int q = kBitsSkew - 1; q > 0; --q) adp[q] = adp[q - 1];
-          adp[0] = ad;
-          Ms[u] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(lds_all) + ad);
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          // One step: U = V & M; V' = (V + U + carry) | (V & ~M), the carry-in mask being the carry-out mask of two steps
-          // ago shifted up one lane, with the strip above's bit for this column in lane 0.  The wave issues in order:
-          // a scalar instruction that reads a mask a vector instruction has just written stalls everything behind it,
-          // so the shift sits here, where the mask is used (in the asm: the compiler would hoist it up to the addition
-          // that made the mask), and the bits for the strip below are collected after the 16 steps.
+          // One step: U = V & M; V' = (V + U + carry) | (V & ~M), the carry-in mask being the carry-out mask of
+          // kBitsSkew steps ago shifted up one lane, with the strip above's bit for this column in lane 0 -- and, in
+          // between, the address of the mask this lane needs 16 steps from now.  The wave issues in order: a scalar
+          // instruction that reads a mask a vector instruction has just written stalls everything behind it, so the
+          // shift sits here, where the mask is used (the compiler would hoist it up to the addition that made the
+          // mask), and the bits for the strip below are collected after the 16 steps.
           const uint32_t bit = (inb >> u) & 1u;
           uint32_t Vn, U, sum;
           unsigned long long co;
+          int nyb, ad = yb;  // lane 0 keeps yb's entry (its source lane does not exist)
           asm volatile(
               "s_lshl_b64 vcc, %[c2], 1\n\t"
-              "s_or_b32 vcc_lo, vcc_lo, %[bit]\n\t"
               "v_and_b32 %[u], %[v], %[m]\n\t"
+              "s_or_b32 vcc_lo, vcc_lo, %[bit]\n\t"
+              "v_mov_b32_dpp %[nyb], %[yb] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
               "v_addc_co_u32 %[sum], %[co], %[v], %[u], vcc\n\t"
+              "v_add_u32_dpp %[ad], %[adk], %[four] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
               "v_bitop3_b32 %[vn], %[sum], %[v], %[m] bitop3:0xf4"  // sum | (v & ~m)
-              : [vn] "=v"(Vn), [u] "=&v"(U), [sum] "=&v"(sum), [co] "=&s"(co)
-              : [c2] "s"(cop[kBitsSkew - 1]), [bit] "s"(bit), [v] "v"(V), [m] "v"(Ms[u])
+              : [vn] "=v"(Vn), [u] "=&v"(U), [sum] "=&v"(sum), [co] "=&s"(co), [nyb] "=&v"(nyb), [ad] "+v"(ad)
+              : [c2] "s"(cop[kBitsSkew - 1]), [bit] "s"(bit), [v] "v"(V), [m] "v"(Mc[u]), [yb] "v"(yb), [adk] "v"(adp[kBitsSkew - 1]),
+                [four] "v"(four)
               : "vcc");
           V = Vn;
+          Mn[u] = lds_mask(ad);
           if (TRACE) __builtin_nontemporal_store(V, tdst + u * 64);
+          yb = nyb;
 #pragma unroll
-          for (int q = kBitsSkew - 1; q > 0; --q) cop[q] = cop[q - 1];
+          for (int q = kBitsSkew - 1; q > 0; --q) adp[q] = adp[q - 1], cop[q] = cop[q - 1];
+          adp[0] = ad;
           cop[0] = co;
           cos[u] = co;
         }
-        // lane 48 + u will write the record of step Ts + u (lane 63's carry out of column Ts + u - 63 * kBitsSkew): bit 63 of the
-        // step's carry-out mask = bit 31 of its upper half, dropped into that lane
+#pragma unroll
+        for (int u = 0; u < 16; ++u) Mc[u] = Mn[u];
+        // lane 48 + u will write the record of step Ts + u (lane 63's carry out of column Ts + u - 63 * kBitsSkew): bit 63
+        // of the step's carry-out mask = bit 31 of its upper half, dropped into that lane
         uint32_t vrec = 0;
 #pragma unroll
         for (int u = 0; u < 16; ++u)
           asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(vrec) : "s"((uint32_t)(cos[u] >> 32)), "n"(48 + u));
         if (!acquire(pend[(sub + 1) % D], Ts + 16, inb)) return false;
-        if (sub == 2) ny = a.yenc[Tb + 64 + lane];
+        if (sub == 0) nyn = a.yenc[Tb + 128 + lane];  // the symbols of the block after next: wanted three sub-blocks from now
         if (TRACE) tdst += 16 * 64;
         // the other lanes write the slot's entry 0, so that the store is one unpredicated instruction
         ho_store(lane >= 48 ? wr + Ts : sink, (int)(vrec >> 31), 0, gen_w);

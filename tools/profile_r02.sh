@@ -21,10 +21,12 @@ B="python3 $ROOT/bench.py --no-cpu"
 run stats_1m   240 --kernel-trace --stats --output-format csv -d "$OUT/stats_1m"   -- $B --steps 3 --warmup 1 --no-batch || exit 1
 run stats_100k 120 --kernel-trace --stats --output-format csv -d "$OUT/stats_100k" -- $B --steps 5 --warmup 1 --no-batch --size 100000 || exit 1
 run stats_100k_unrel 120 --kernel-trace --stats --output-format csv -d "$OUT/stats_100k_unrel" -- $B --steps 5 --warmup 1 --no-batch --size 100000 --unrelated || exit 1
+run stats_lcs1m 240 --kernel-trace --stats --output-format csv -d "$OUT/stats_lcs1m" -- $B --steps 3 --warmup 1 --no-batch --kind lcs || exit 1
 run stats_batch 240 --kernel-trace --stats --output-format csv -d "$OUT/stats_batch" -- $B --steps 2 --warmup 1 --workload batch || exit 1
 SQ="SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU SQ_WAVES"
-for w in 1m 100k batch; do
+for w in 1m 100k lcs1m batch; do
   case $w in
+    lcs1m) ARGS="--steps 1 --warmup 0 --no-batch --kind lcs" ;;
     1m) ARGS="--steps 1 --warmup 0 --no-batch" ;;
     100k) ARGS="--steps 1 --warmup 0 --no-batch --size 100000" ;;
     batch) ARGS="--steps 1 --warmup 0 --workload batch" ;;

@@ -97,7 +97,47 @@ def batch(pairs, calls):
     print("batch", {k: v for k, v in out["batch"].items() if isinstance(v, float)})
 
 
+def lcs_bits(m, n):
+    st, f = stats("stats_lcs1m")
+    shutil.copy(f, DST / "r02_lcs1m_kernel_stats.csv")
+    name = next(k for k in st if "lcs_bits_persistent" in k)
+    avg_ms = float(st[name]["AverageNs"]) / 1e6
+    c = defaultdict(float)
+    for p in ("write", "fetch", "sq"):
+        t, nd = counters(f"pmc_{p}_lcs1m")
+        assert nd[name] == 1, nd
+        c.update(t[name])
+    S, steps = -(-m // 2048), ((n + 126 + 63) // 64) * 64
+    wbytes, fbytes = c["WRITE_SIZE"] * 1024, c["FETCH_SIZE"] * 1024 * 2
+    algo = float(S) * steps * 256
+    out = {
+        "command": "tools/profile_r02.sh: one rocprofv3 pass each for --pmc WRITE_SIZE | --pmc FETCH_SIZE | --pmc SQ_* GRBM_GUI_ACTIVE on "
+                   "`python3 bench.py --no-cpu --steps 1 --warmup 0 --no-batch --kind lcs`; kernel-trace stats from a run of its own",
+        "workload": f"LCS {m}x{n} as bit vectors (sa_lcsbits.hip), {S} strips of 2048 rows, {steps} steps each, one launch; {avg_ms:.2f} ms "
+                    "(kernel-trace average, r02_lcs1m_kernel_stats.csv)",
+        "kernel": name,
+        "counters": dict(sorted(c.items())),
+        "derived": {
+            "WRITE_SIZE_bytes": wbytes,
+            "FETCH_SIZE_bytes_x2_gfx950_correction": fbytes,
+            "hbm_traffic_bytes_per_launch": wbytes + fbytes,
+            "algorithmic_bytes_per_launch": algo,
+            "algorithmic_note": "the traceback record: one dword per lane per step = 1 bit per cell (+ the lane skew and the padding of the last strip)",
+            "traffic_over_algorithmic": (wbytes + fbytes) / algo,
+            "hbm_GBps_at_kernel_trace_time": algo / (avg_ms / 1e3) / 1e9,
+            "valu_instr_per_column_step": c["SQ_INSTS_VALU"] / (S * steps),
+            "salu_instr_per_column_step": c["SQ_INSTS_SALU"] / (S * steps),
+            "wave_cycles_issuing_valu": c["SQ_ACTIVE_INST_VALU"] / c["SQ_WAVE_CYCLES"] if c["SQ_WAVE_CYCLES"] else None,
+            "wave_cycles_waiting": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"] if c["SQ_WAVE_CYCLES"] else None,
+            "wave_cycles_per_column_step": c["SQ_WAVE_CYCLES"] / (S * steps),
+        },
+    }
+    (DST / "r02_lcs1m_pmc.json").write_text(json.dumps(out, indent=1))
+    print("lcs1m", name, f"{avg_ms:.2f} ms", {k: round(v, 4) for k, v in out["derived"].items() if isinstance(v, float) and v < 1e6})
+
+
 sys.path.insert(0, str(ROOT))
+lcs_bits(1_000_000, 999_747)
 pair("1m", "void sa::fill_persistent<0, 8, 0>", 1_000_000, 999_747, 8, 12)
 pair("100k", "void sa::fill_persistent<0, 2, 0>", 100_000, 100_085, 2, 12)
 st, f = stats("stats_100k_unrel")
