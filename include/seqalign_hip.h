@@ -97,7 +97,8 @@ int sa_set_stream(sa_ctx* ctx, void* hip_stream); /* hipStream_t; NULL = the ctx
 void sa_free_result(sa_result* r);
 /* frees the ctx's cached device workspaces (they are re-allocated on demand) */
 int sa_release_workspace(sa_ctx* ctx);
-/* tuning overrides, 0 = automatic: rows per lane K in {1,2,4,8}, tile steps C multiple of 64 */
+/* tuning overrides, 0 = automatic: rows per lane K in {1,2,4,8} (16: the LCS cell kernel over small alphabets only,
+ * 8 elsewhere), tile steps C multiple of 64.  A forced K also keeps sa_lcs on the cell-by-cell kernels. */
 int sa_set_tuning(sa_ctx* ctx, int rows_per_lane, int tile_steps);
 /* engine options: "persistent" 0/1 (fill as one persistent strip-pipelined launch instead of one
  * launch per tile diagonal; same results), "waves_per_simd" 1..4 (grid of the persistent launch),
@@ -105,7 +106,10 @@ int sa_set_tuning(sa_ctx* ctx, int rows_per_lane, int tile_steps);
  * "trace_budget_mb" (single pair: bytes of 2-bit codes a call may hold, 0 = 88 % of the device; a pair
  * whose codes exceed it is filled with checkpoints -- the bottom row of every strip -- and the
  * traceback recomputes the strips it crosses, a band at a time: same results, about twice the fill
- * work, and e.g. 2 Mb x 2 Mb on one GPU), "checkpoint_band" N > 0 (always take that path, N strips per band) */
+ * work, and e.g. 2 Mb x 2 Mb on one GPU), "checkpoint_band" N > 0 (always take that path, N strips per band),
+ * "lcs_bits" 0/1 (default 1: sa_lcs on a whole pair over at most 63 distinct bytes runs as bit-vector
+ * arithmetic -- 32 rows per lane, sa_result.rows_per_lane = 32, one bit of traceback record per cell; same
+ * results as the cell-by-cell kernels, which still serve stripes, checkpointed runs, dumps and larger alphabets) */
 int sa_set_option(sa_ctx* ctx, const char* name, int64_t value);
 
 /* The reference's two built-in scoring schemes with default penalties -5/-1

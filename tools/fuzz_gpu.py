@@ -1,5 +1,5 @@
 """Randomised GPU-vs-oracle parity: shapes, alphabets, gap settings, rows per lane, both fill
-schedules, checkpoint bands, score-only calls.  `python tools/fuzz_gpu.py SECONDS [SEED]`; prints a
+schedules, checkpoint bands, score-only calls, bit-vector / cell-by-cell LCS.  `python tools/fuzz_gpu.py SECONDS [SEED]`; prints a
 line per 200 cases and stops at the first mismatch with the reproducer."""
 import sys
 import time
@@ -37,13 +37,14 @@ while time.time() - t0 < budget:
     if not y:
         y = alpha[0]
     go, ge = GAPS[int(rng.integers(0, len(GAPS)))]
-    K = int(rng.choice([0, 0, 1, 2, 4, 8]))
+    K = int(rng.choice([0, 0, 0, 1, 2, 4, 8, 16]))  # 0: automatic (LCS: the bit-vector kernel); 16: LCS only, 8 elsewhere
     persistent = int(rng.random() < 0.7)
     band = int(rng.choice([0, 0, 0, 1, 2, 5]))
     flags = 2 if rng.random() < 0.1 else 0
     eng.set_tuning(K, 0)
     eng.set_option("persistent", persistent)
     eng.set_option("checkpoint_band", band)
+    eng.set_option("lcs_bits", int(rng.random() < 0.85))
     if kind == "lcs":
         g, o = eng.lcs(x, y, flags=flags), orc.lcs(x, y)
     else:
