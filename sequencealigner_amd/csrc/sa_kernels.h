@@ -1062,14 +1062,16 @@ __device__ __forceinline__ void ballot_eq_to_lane(uint32_t& lo, uint32_t& hi, ui
 
 // ---- bit-vector LCS (sa_lcsbits.hip): the same walker over one bit per cell ----
 // The fill stores, per column, the vertical differences of the L matrix as bit vectors: bit (r & 31) of dword
-// [strip][step c + kBitsSkew * lane][lane] (row r 0-based in word g = r >> 5 = strip * 64 + lane, column c 0-based) is CLEAR iff
+// [strip][t / 4][lane][t % 4], t = step c + kBitsSkew * lane (row r 0-based in word g = r >> 5 = strip * 64 + lane, column c 0-based) is CLEAR iff
 // L[r+1][c+1] = L[r][c+1] + 1.  The reference's pointer at a cell (main.cpp:1577-1587) follows from it: diagonal iff
 // the symbols match, else up iff L[i-1][j] >= L[i][j-1], which in a mismatch cell (L[i][j] = max of the two) is
 // "the vertical difference is 0", i.e. the bit is SET; else left.
+constexpr int kBitsStripPad = 0;  // dwords between the records of consecutive strips (17 x 256 B, against channel hot spots: no change)
 constexpr int kBitsSkew = 2;  // the fill's skew (sa_lcsbits.hip): lane l meets column c at step c + kBitsSkew * l
 __device__ __forceinline__ uint32_t bits_word(const TraceArgs& a, int g, int c) {
   const int sidx = g >> 6, l = g & 63;
-  return a.trace[((size_t)sidx * a.W + (c + kBitsSkew * l)) * 64 + l];
+  const int t = c + kBitsSkew * l;
+  return a.trace[(size_t)sidx * ((size_t)a.W * 64 + kBitsStripPad) + (size_t)(t & ~3) * 64 + l * 4 + (t & 3)];
 }
 // op code (0 diagonal, 1 left, 2 up) of cell (i, j), 1-based
 __device__ __forceinline__ uint32_t bits_code(const TraceArgs& a, int i, int j) {

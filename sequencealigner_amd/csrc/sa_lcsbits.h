@@ -8,6 +8,7 @@ namespace sa {
 
 constexpr int kBitsRowsPerLane = 32;                      // one dword of vertical differences per lane
 constexpr int kBitsStripRows = 64 * kBitsRowsPerLane;     // 2048 rows per strip (wavefront)
+constexpr int kBitsSub = 32;                              // steps between record hand-offs (16 or 32)
 constexpr int kBitsRecord0 = 256;                         // index of column 0 in a slot of hand-off records
 constexpr int kBitsMaxAlpha = 64;                         // profile symbols incl. the padding symbol: 16 KB of LDS per wave
 

@@ -32,7 +32,9 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
   uint32_t* lds = lds_all + (threadIdx.x >> 6) * (a.alpha * 64);
   const int NB = a.W / 64;  // steps per strip: n + 2 * 63, rounded up to whole blocks
   const int ypad = (a.alpha - 1) * 256;  // LDS byte offset of the padding symbol's (empty) masks
-  constexpr int D = 4;                   // records are requested four sub-blocks ahead
+  constexpr int SUBN = kBitsSub;         // steps per sub-block (record hand-off granularity)
+  constexpr int NSUB = 64 / SUBN;        // sub-blocks per block of 64 steps
+  constexpr int D = NSUB;                // records are requested 64 steps ahead (D must divide NSUB: static register choice)                  
 
   while (true) {
     int s = 0;
@@ -47,21 +49,21 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
     // slots and generations as in fill_persistent (ho_store): matrix row 0 is "strip -1", slot 0, generation 0
     const int gen_r = ho_gen((s / a.ring) % 3), gen_w = ho_gen(((s + 1) / a.ring) % 3);
     // record of column c at index c + kBitsRecord0 of a slot; lane 63 meets column t - 63 * kBitsSkew at step t
-    const int2* rd = a.bot2 + (size_t)(s % a.ring) * a.NP + kBitsRecord0 + min(lane, 15);
+    const int2* rd = a.bot2 + (size_t)(s % a.ring) * a.NP + kBitsRecord0 + min(lane, SUBN - 1);
     int2* const sink = a.bot2 + (size_t)((s + 1) % a.ring) * a.NP;  // entry 0 of the slot: nobody reads it
-    int2* const wr = sink + (kBitsRecord0 - 63 * kBitsSkew) + (lane - 48);
+    int2* const wr = sink + (kBitsRecord0 - 63 * kBitsSkew) + (lane - (64 - SUBN));
     // Only the first dword of a record is used here (carry bit | generation) and only that is loaded: with the 8-byte
     // load the second register is dead, gets reused at once, and the write-after-write wait for the load in flight
     // (s_waitcnt vmcnt(0), 0.85 us) lands at the top of every sub-block -- 53 of the 54 ns per step, measured.
     auto rec_load = [](const int2* p) { return ld_coherent(reinterpret_cast<const int*>(p)); };
     int pend[D];
 #pragma unroll
-    for (int j = 0; j < D; ++j) pend[j] = rec_load(rd + 16 * j);
+    for (int j = 0; j < D; ++j) pend[j] = rec_load(rd + SUBN * j);
 
     // carry bits of the 16 columns of a sub-block, from the records in `cur` (lanes 0..15); requests the records
     // D sub-blocks further on into the same registers.  false: the bounded wait expired.
     auto acquire = [&](int& cur, const int Ts, uint32_t& inb) -> bool {
-      const int need = (lane < 16) & (Ts + lane < a.n);
+      const int need = (lane < SUBN) & (Ts + lane < a.n);
       if (__builtin_expect(__ballot(need & ho_stale(cur, gen_r)) != 0ull, 0)) {
         int spins = 0;
         while (true) {
@@ -73,7 +75,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
         }
       }
       inb = (uint32_t)__ballot(need & (cur & 1));
-      cur = rec_load(rd + Ts + 16 * D);
+      cur = rec_load(rd + Ts + SUBN * D);
       return true;
     };
 
@@ -94,10 +96,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
     int yb = a.yenc[lane] * 256 + lds0;  // block 0
     int ny = a.yenc[64 + lane];          // block 1
     int nyn = 0;
-    uint32_t Mc[16], Mn[16];             // masks of the current / the next sub-block
+    uint32_t Mc[SUBN], Mn[SUBN];             // masks of the current / the next sub-block
     auto lds_mask = [](int ad) { return *(lds_u32*)(uintptr_t)(uint32_t)ad; };
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {  // sub-block 0
+    for (int u = 0; u < SUBN; ++u) {  // sub-block 0
       const int nyb = dpp_shl1_any(yb);
       int ad = yb;  // lane 0 keeps this (its source lane does not exist)
       asm("v_add_u32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(ad) : "v"(adp[kBitsSkew - 1]), "v"(four));
@@ -113,15 +115,16 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
     unsigned long long cop[kBitsSkew];
 #pragma unroll
     for (int q = 0; q < kBitsSkew; ++q) cop[q] = 0;
-    uint32_t* tdst = TRACE ? a.trace + ((size_t)(s - a.trace_s0) * a.W) * 64 + lane : nullptr;
+    uint32_t* tdst = TRACE ? a.trace + ((size_t)(s - a.trace_s0) * ((size_t)a.W * 64 + kBitsStripPad)) + lane * 4 : nullptr;
+    uint32_t* tdst2 = TRACE ? tdst + 16 * 64 : nullptr;
 
 #pragma unroll 1
     for (int b = 0; b < NB && !dead; ++b) {
       const int Tb = 64 * b;
       auto sub_block = [&](auto subc) -> bool {
         constexpr int sub = decltype(subc)::value;
-        const int Ts = Tb + 16 * sub;
-        if (sub == 3) {  // the mask stream enters the next block
+        const int Ts = Tb + SUBN * sub;
+        if (sub == NSUB - 1) {  // the mask stream enters the next block
           yb = ny * 256 + lds0;
           ny = nyn;
         }
@@ -133,8 +136,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
                    (uint32_t)__builtin_amdgcn_readfirstlane((int)cop[q]);
         inb = (uint32_t)__builtin_amdgcn_readfirstlane((int)inb);
         unsigned long long cos[16];
+        uint32_t vrec = 0;
+        uint32_t Vh[4];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < SUBN; ++u) {
           // One step: U = V & M; V' = (V + U + carry) | (V & ~M), the carry-in mask being the carry-out mask of
           // kBitsSkew steps ago shifted up one lane, with the strip above's bit for this column in lane 0 -- and, in
           // between, the address of the mask this lane needs 16 steps from now.  The wave issues in order: a scalar
@@ -159,31 +164,43 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
               : "vcc");
           V = Vn;
           Mn[u] = lds_mask(ad);
-          if (TRACE) __builtin_nontemporal_store(V, tdst + u * 64);
+          // the record leaves four steps at a time, [strip][step / 4][lane][step % 4]: 1 KB in one piece per store
+          // instruction (a quarter of the memory operations of a dword per step; 16 steps at a time as 4 x 16 bytes at a
+          // 64-byte lane stride measured 70 ms against 47: every instruction then touches 64 lines in part)
+          Vh[u & 3] = V;
+          if (TRACE && (u & 3) == 3) {
+            const u32x4 v4 = {Vh[0], Vh[1], Vh[2], Vh[3]};
+            __builtin_nontemporal_store(v4, reinterpret_cast<u32x4*>((u < 16 ? tdst : tdst2) + ((u & 15) >> 2) * 256));  // offsets reach 4 KB
+          }
           yb = nyb;
 #pragma unroll
           for (int q = kBitsSkew - 1; q > 0; --q) adp[q] = adp[q - 1], cop[q] = cop[q - 1];
           adp[0] = ad;
           cop[0] = co;
-          cos[u] = co;
+          cos[u & 15] = co;
+          // lane 64 - SUBN + u will write the record of step Ts + u (lane 63's carry out of column Ts + u - 63 * kBitsSkew):
+          // bit 63 of the step's carry-out mask = bit 31 of its upper half, dropped into that lane -- 16 steps at a time,
+          // when the oldest of the 16 masks is long since written
+          if ((u & 15) == 15) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q)
+              asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(vrec) : "s"((uint32_t)(cos[q] >> 32)), "n"(64 - SUBN + u - 15 + q));
+          }
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) Mc[u] = Mn[u];
-        // lane 48 + u will write the record of step Ts + u (lane 63's carry out of column Ts + u - 63 * kBitsSkew): bit 63
-        // of the step's carry-out mask = bit 31 of its upper half, dropped into that lane
-        uint32_t vrec = 0;
-#pragma unroll
-        for (int u = 0; u < 16; ++u)
-          asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(vrec) : "s"((uint32_t)(cos[u] >> 32)), "n"(48 + u));
-        if (!acquire(pend[(sub + 1) % D], Ts + 16, inb)) return false;
+        for (int u = 0; u < SUBN; ++u) Mc[u] = Mn[u];
+        if (!acquire(pend[(sub + 1) % D], Ts + SUBN, inb)) return false;
         if (sub == 0) nyn = a.yenc[Tb + 128 + lane];  // the symbols of the block after next: wanted three sub-blocks from now
-        if (TRACE) tdst += 16 * 64;
+        if (TRACE) tdst += SUBN * 64, tdst2 += SUBN * 64;
         // the other lanes write the slot's entry 0, so that the store is one unpredicated instruction
-        ho_store(lane >= 48 ? wr + Ts : sink, (int)(vrec >> 31), 0, gen_w);
+        ho_store(lane >= 64 - SUBN ? wr + Ts : sink, (int)(vrec >> 31), 0, gen_w);
         return true;
       };
-      dead = !(sub_block(std::integral_constant<int, 0>()) && sub_block(std::integral_constant<int, 1>()) &&
-               sub_block(std::integral_constant<int, 2>()) && sub_block(std::integral_constant<int, 3>()));
+      if constexpr (NSUB == 4)
+        dead = !(sub_block(std::integral_constant<int, 0>()) && sub_block(std::integral_constant<int, 1>()) &&
+                 sub_block(std::integral_constant<int, 2>()) && sub_block(std::integral_constant<int, 3>()));
+      else
+        dead = !(sub_block(std::integral_constant<int, 0>()) && sub_block(std::integral_constant<int, 1>()));
     }
     if (dead) {
       if (lane == 0) st_coherent(a.err, 1);

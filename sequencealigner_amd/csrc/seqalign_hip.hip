@@ -853,7 +853,7 @@ int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n,
   const int Tend = bits_steps(n);
   const int NP = bits_slot_len(n);
   const bool no_tb = (flags & SA_FLAG_NO_TRACEBACK) != 0;
-  const size_t trace_bytes = no_tb ? 0 : (size_t)S * Tend * 64 * 4;
+  const size_t trace_bytes = no_tb ? 0 : (size_t)S * ((size_t)Tend * 64 + kBitsStripPad) * 4;
   size_t budget = ctx->trace_budget;
   if (!budget) {
     size_t free_b = 0, total_b = 0;
