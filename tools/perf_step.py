@@ -8,6 +8,7 @@ import sequencealigner_amd as sa
 from sequencealigner_amd.synth import dna_pair
 
 eng = sa.Engine(0)
+eng.set_option("lcs_bits", 0)
 x, y = dna_pair(1_000_000, seed=1234)
 for kind in ("nw", "sw", "lcs"):
     row = []
@@ -18,9 +19,12 @@ for kind in ("nw", "sw", "lcs"):
         row.append(f"K={K} {t * 1e6 / (len(y) + 63):.1f}")
     print(f"{kind} ns/step, one strip:", "  ".join(row), flush=True)
 eng.set_tuning(0, 0)
+eng.set_option("lcs_bits", 0)
 for n in (100_000, 1_000_000):
-    r = min((eng.nw(x[:n], y[:n], "dna") for _ in range(2)), key=lambda r: r.kernel_fill_ms)
-    print(f"nw {n}: K={r.rows_per_lane} fill kernel {r.kernel_fill_ms:.2f} ms", flush=True)
+    for K in (0, 8, 16):
+        eng.set_tuning(K, 0)
+        r = min((eng.nw(x[:n], y[:n], "dna") for _ in range(2)), key=lambda r: r.kernel_fill_ms)
+        print(f"nw {n}: K={r.rows_per_lane} (asked {K}) fill kernel {r.kernel_fill_ms:.2f} ms", flush=True)
 for n in (100_000, 1_000_000):
     for K in (0, 8, 16):
         eng.set_tuning(K, 0)
