@@ -18,7 +18,8 @@ void bits_launch_profile(hipStream_t st, const uint8_t* xs, int m, int alpha, in
 int bits_steps(int n);
 int bits_slot_len(int n);
 // the fill: FillArgs as for fill_persistent (W = steps per strip, trace = [S][W][64] dwords or null: score only)
-void bits_launch_fill(hipStream_t st, int grid_blocks, const FillArgs& a);
+// waves_per_block: 1, 2 or 4 waves per workgroup (each wave works on its own; fewer per workgroup spreads them over more CUs)
+void bits_launch_fill(hipStream_t st, int grid_blocks, int waves_per_block, const FillArgs& a);
 // the walker over that format (TraceArgs::xs / ys / W set)
 void bits_launch_traceback(hipStream_t st, const TraceArgs& t);
 

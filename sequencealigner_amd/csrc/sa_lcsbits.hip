@@ -243,12 +243,12 @@ void bits_launch_profile(hipStream_t st, const uint8_t* xs, int m, int alpha, in
   hipLaunchKernelGGL(build_bits_profile, dim3(blocks), dim3(256), 0, st, xs, m, alpha, S, prof);
 }
 
-void bits_launch_fill(hipStream_t st, int grid_blocks, const FillArgs& a) {
-  const size_t lds = (size_t)a.alpha * 64 * 4 * kWavesPerBlock;
+void bits_launch_fill(hipStream_t st, int grid_blocks, int waves_per_block, const FillArgs& a) {
+  const size_t lds = (size_t)a.alpha * 64 * 4 * waves_per_block;
   if (a.trace)
-    hipLaunchKernelGGL(lcs_bits_persistent<true>, dim3(grid_blocks), dim3(64 * kWavesPerBlock), lds, st, a);
+    hipLaunchKernelGGL(lcs_bits_persistent<true>, dim3(grid_blocks), dim3(64 * waves_per_block), lds, st, a);
   else
-    hipLaunchKernelGGL(lcs_bits_persistent<false>, dim3(grid_blocks), dim3(64 * kWavesPerBlock), lds, st, a);
+    hipLaunchKernelGGL(lcs_bits_persistent<false>, dim3(grid_blocks), dim3(64 * waves_per_block), lds, st, a);
 }
 
 void bits_launch_traceback(hipStream_t st, const TraceArgs& t) {

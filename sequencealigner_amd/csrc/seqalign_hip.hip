@@ -68,6 +68,7 @@ struct sa_ctx {
   int force_K = 0, force_C = 0;
   size_t batch_trace_budget = (size_t)32 << 30;  // sa_sw_batch_align: device bytes of direction codes per chunk
   int persist = 1;  // 1: persistent strip pipeline (one launch) where it applies
+  int bits_wpb = 0; // bit-vector LCS: waves per workgroup, 0 = automatic (option "lcs_bits_waves_per_block", for measurements)
   int lcs_bits = 1; // 1: LCS of a whole pair over at most 63 distinct bytes runs as bit-vector arithmetic (sa_lcsbits.hip)
   int wps = 1;      // persistent kernel: waves per SIMD to launch
   int n_cu = 256;
@@ -861,8 +862,13 @@ int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n,
     budget = (size_t)((double)total_b * 0.88);
   }
   if (trace_bytes > budget) return SA_OK;
-  const int grid_blocks = std::min((S + kWavesPerBlock - 1) / kWavesPerBlock, ctx->n_cu * std::max(1, ctx->wps));
-  const int ring = std::min(S + 1, grid_blocks * kWavesPerBlock + 2);
+  // Waves per workgroup: as few as still give every strip a wave in one round.  A CU sustains ~25 GB/s of record writes
+  // (so does a plain fill: 6.9 TB/s over 256 CUs), and 489 strips as 123 workgroups of four waves use 123 CUs: 2.7 TB/s,
+  // 47 ms at 1 Mb x 1 Mb; as 245 workgroups of two waves they use 245.
+  const int cap = ctx->n_cu * std::max(1, ctx->wps);
+  const int wpb = ctx->bits_wpb ? ctx->bits_wpb : (S <= 2 * cap ? 2 : kWavesPerBlock);  // (single-wave workgroups are not guaranteed a SIMD of their own)
+  const int grid_blocks = std::min((S + wpb - 1) / wpb, cap);
+  const int ring = std::min(S + 1, grid_blocks * wpb + 2);
   const size_t rows_pad = (size_t)S * kBitsStripRows;
   int rc;
   {
@@ -918,7 +924,7 @@ int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n,
   a.err = (int*)ctx->small.p + 40;
   a.spin_limit = 1 << 22;
   HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
-  bits_launch_fill(st, grid_blocks, a);
+  bits_launch_fill(st, grid_blocks, wpb, a);
   HIPCK(ctx, hipGetLastError());
   HIPCK(ctx, hipEventRecord(ctx->ev[2], st));
   out->n_launches = 1;
@@ -1963,6 +1969,9 @@ int sa_set_option(sa_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return SA_ERR_ARG;
   if (!strcmp(name, "persistent")) {
     c->persist = value != 0;
+  } else if (!strcmp(name, "lcs_bits_waves_per_block")) {
+    if (!(value == 0 || value == 1 || value == 2 || value == 4)) return fail(c, SA_ERR_ARG, "lcs_bits_waves_per_block must be 0, 1, 2 or 4");
+    c->bits_wpb = (int)value;
   } else if (!strcmp(name, "lcs_bits")) {  // 0: LCS always through the cell-by-cell kernels
     c->lcs_bits = value != 0;
   } else if (!strcmp(name, "checkpoint_band")) {  // 0: checkpoint only when the codes do not fit
