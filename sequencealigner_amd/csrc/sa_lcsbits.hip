@@ -60,9 +60,11 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
 #pragma unroll
     for (int j = 0; j < D; ++j) pend[j] = rec_load(rd + SUBN * j);
 
-    // carry bits of the 16 columns of a sub-block, from the records in `cur` (lanes 0..15); requests the records
-    // D sub-blocks further on into the same registers.  false: the bounded wait expired.
-    auto acquire = [&](int& cur, const int Ts, uint32_t& inb) -> bool {
+    // carry bits of the columns of a sub-block, from the records in `cur` (lanes 0..SUBN-1); requests the records
+    // D sub-blocks further on into the same registers.  A bounded wait that expires raises `dead` (looked at once per
+    // block: the sub-block boundary is straight-line code but for this one branch, which is not taken).
+    bool dead = false;
+    auto acquire = [&](int& cur, const int Ts, uint32_t& inb) {
       const int need = (lane < SUBN) & (Ts + lane < a.n);
       if (__builtin_expect(__ballot(need & ho_stale(cur, gen_r)) != 0ull, 0)) {
         int spins = 0;
@@ -71,12 +73,14 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
           cur = rec_load(rd + Ts);
           if (__ballot(need & ho_stale(cur, gen_r)) == 0ull) break;
           // (wave-uniform on purpose: everything derived from the exit stays in scalar registers)
-          if (++spins > a.spin_limit || ((spins & 255) == 0 && __builtin_amdgcn_readfirstlane(ld_coherent(a.err)) != 0)) return false;
+          if (++spins > a.spin_limit || ((spins & 255) == 0 && __builtin_amdgcn_readfirstlane(ld_coherent(a.err)) != 0)) {
+            dead = true;
+            break;
+          }
         }
       }
       inb = (uint32_t)__ballot(need & (cur & 1));
       cur = rec_load(rd + Ts + SUBN * D);
-      return true;
     };
 
     uint32_t V = 0xffffffffu;  // column 0 of L is all zeros: no vertical step anywhere
@@ -110,7 +114,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
       Mc[u] = lds_mask(ad);
     }
     uint32_t inb = 0;
-    bool dead = !acquire(pend[0], 0, inb);
+    acquire(pend[0], 0, inb);
     // carry-out masks of the last kBitsSkew steps (bit l = carry out of lane l): the oldest, shifted left by one, is due now
     unsigned long long cop[kBitsSkew];
 #pragma unroll
@@ -121,7 +125,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
 #pragma unroll 1
     for (int b = 0; b < NB && !dead; ++b) {
       const int Tb = 64 * b;
-      auto sub_block = [&](auto subc) -> bool {
+      auto sub_block = [&](auto subc) {
         constexpr int sub = decltype(subc)::value;
         const int Ts = Tb + SUBN * sub;
         if (sub == NSUB - 1) {  // the mask stream enters the next block
@@ -189,18 +193,18 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
         }
 #pragma unroll
         for (int u = 0; u < SUBN; ++u) Mc[u] = Mn[u];
-        if (!acquire(pend[(sub + 1) % D], Ts + SUBN, inb)) return false;
+        acquire(pend[(sub + 1) % D], Ts + SUBN, inb);
         if (sub == 0) nyn = a.yenc[Tb + 128 + lane];  // the symbols of the block after next: wanted three sub-blocks from now
         if (TRACE) tdst += SUBN * 64, tdst2 += SUBN * 64;
         // the other lanes write the slot's entry 0, so that the store is one unpredicated instruction
         ho_store(lane >= 64 - SUBN ? wr + Ts : sink, (int)(vrec >> 31), 0, gen_w);
-        return true;
       };
-      if constexpr (NSUB == 4)
-        dead = !(sub_block(std::integral_constant<int, 0>()) && sub_block(std::integral_constant<int, 1>()) &&
-                 sub_block(std::integral_constant<int, 2>()) && sub_block(std::integral_constant<int, 3>()));
-      else
-        dead = !(sub_block(std::integral_constant<int, 0>()) && sub_block(std::integral_constant<int, 1>()));
+      sub_block(std::integral_constant<int, 0>());
+      sub_block(std::integral_constant<int, 1>());
+      if constexpr (NSUB == 4) {
+        sub_block(std::integral_constant<int, 2>());
+        sub_block(std::integral_constant<int, 3>());
+      }
     }
     if (dead) {
       if (lane == 0) st_coherent(a.err, 1);
