@@ -109,7 +109,8 @@ int sa_set_tuning(sa_ctx* ctx, int rows_per_lane, int tile_steps);
  * work, and e.g. 2 Mb x 2 Mb on one GPU), "checkpoint_band" N > 0 (always take that path, N strips per band),
  * "lcs_bits" 0/1 (default 1: sa_lcs on a whole pair over at most 63 distinct bytes runs as bit-vector
  * arithmetic -- 32 rows per lane, sa_result.rows_per_lane = 32, one bit of traceback record per cell; same
- * results as the cell-by-cell kernels, which still serve stripes, checkpointed runs, dumps and larger alphabets) */
+ * results as the cell-by-cell kernels, which still serve stripes, checkpointed runs, dumps and larger alphabets),
+ * "lcs_bits_waves_per_block" 0 (automatic) / 1 / 2 / 4 (measurements: how many strips share a workgroup there) */
 int sa_set_option(sa_ctx* ctx, const char* name, int64_t value);
 
 /* The reference's two built-in scoring schemes with default penalties -5/-1
