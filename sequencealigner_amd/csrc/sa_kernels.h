@@ -755,11 +755,21 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
 }
 
 // host-initialised records of matrix row 0 (slot 0, generation 0): H[0][c+1] at index c + 64
-static __global__ void init_row0_records(int2* __restrict__ dst, const int* __restrict__ h4, int n, int hconst, int f) {
+// h4 given: the host's chain; else H[0][c+1] = hconst + c * hstep in register scale (NW with integral penalties:
+// 4 (go + c ge), main.cpp:719-725; SW: 0; LCS: the tag)
+static __global__ void init_row0_records(int2* __restrict__ dst, const int* __restrict__ h4, int n, int hconst, int f, int hstep = 0) {
   for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < n; c += gridDim.x * blockDim.x) {
-    const int h = h4 ? h4[c] : hconst;
+    const int h = h4 ? h4[c] : hconst + c * hstep;
     dst[64 + c] = make_int2(h & 0x3fffffff, f);
   }
+}
+
+// left border of the whole matrix for integral penalties, written on the device: row i holds (H[i][0], E[i][0]) =
+// (h1 + (i - 1) hstep, e) for i >= 1 and (0, e) for row 0 -- NW: go + (i - 1) max(go, ge), the closed form of the
+// chain main.cpp:601-606 builds when nothing is truncated; SW / LCS: zeros
+static __global__ void init_left_border(int2* __restrict__ lb, int m, int h1, int hstep, int e) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i <= m; i += gridDim.x * blockDim.x)
+    lb[i] = make_int2(i == 0 ? 0 : h1 + (i - 1) * hstep, e);
 }
 
 // Column stripes with the persistent kernel: the two ends of a border hand-off, each a one-wave

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -590,8 +591,11 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   // E[i][0]: main.cpp:619 (-inf) / :1105 (0).  The kernel multiplies border values by 4, so -inf
   // is handed over as INT_MIN/8.
   const int e_border = (kind == KIND_NW) ? kNeg / 4 : 0;
+  // Whole matrix, integral penalties, persistent schedule: both borders are closed forms and are written on the device
+  // (rowb / colb are empty then); otherwise the host's chains are uploaded.
+  const bool dev_borders = rowb.empty();
   std::vector<int> lbh;
-  if (first) {
+  if (first && !dev_borders) {
     lbh.resize(((size_t)m + 1) * 2);
     for (int i = 0; i <= m; ++i) {
       lbh[2 * (size_t)i] = colb[i];
@@ -603,7 +607,12 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   HIPCK(ctx, hipMemcpyAsync(ctx->xenc.p, xe.data(), xe.size(), hipMemcpyHostToDevice, st));
   HIPCK(ctx, hipMemcpyAsync(ctx->yenc.p, ye.data(), ye.size(), hipMemcpyHostToDevice, st));
   const int2* lb;
-  if (first) {
+  const int gi_open = sc ? (int)sc->gap_open : 0, gi_ext = sc ? (int)sc->gap_extend : 0;
+  if (first && dev_borders) {
+    hipLaunchKernelGGL(init_left_border, dim3(std::min((m + 256) / 256, 2048)), dim3(256), 0, st, (int2*)ctx->lbuf.p, m,
+                       kind == KIND_NW ? gi_open : 0, kind == KIND_NW ? std::max(gi_open, gi_ext) : 0, e_border);
+    lb = (const int2*)ctx->lbuf.p;
+  } else if (first) {
     HIPCK(ctx, hipMemcpyAsync(ctx->lbuf.p, lbh.data(), lbh.size() * 4, hipMemcpyHostToDevice, st));
     lb = (const int2*)ctx->lbuf.p;
   } else {
@@ -620,7 +629,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   int* row0H = botH + (size_t)(ring - 1) * NP;
   int* row0F = botF + (size_t)(ring - 1) * NP;
   std::vector<int> rowb4;
-  if (kind == KIND_NW) {
+  if (kind == KIND_NW && !dev_borders) {
     rowb4.resize((size_t)n);
     for (int j = 0; j < n; ++j) rowb4[j] = 4 * rowb[j + 1];
   }
@@ -629,14 +638,15 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
     // into slot 0 with generation 0, as "strip -1".
     HIPCK(ctx, hipMemsetD32Async((hipDeviceptr_t)bot2, (int)0xC0000000u, (size_t)2 * ring * NP, st));
     const int* d_h4 = nullptr;
-    if (kind == KIND_NW) {
+    if (kind == KIND_NW && !dev_borders) {
       if ((rc = ensure(ctx, ctx->colb, (size_t)n * 4))) return rc;
       HIPCK(ctx, hipMemcpyAsync(ctx->colb.p, rowb4.data(), (size_t)n * 4, hipMemcpyHostToDevice, st));
       d_h4 = (const int*)ctx->colb.p;
     }
     // LCS registers hold 4 * L + 1 (sa_kernels.h): row 0 is all ones; SW: zeros; F[0][j] = -inf (NW) / 0
     hipLaunchKernelGGL(init_row0_records, dim3(std::min((n + 255) / 256, 2048)), dim3(256), 0, st, bot2, d_h4, n,
-                       kind == KIND_LCS ? 1 : 0, kind == KIND_NW ? kNeg : 0);
+                       kind == KIND_LCS ? 1 : (kind == KIND_NW && dev_borders ? 4 * gi_open : 0), kind == KIND_NW ? kNeg : 0,
+                       kind == KIND_NW && dev_borders ? 4 * gi_ext : 0);
   } else {
     if (kind == KIND_LCS) {
       if (ring == 2)
@@ -1153,6 +1163,12 @@ int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t
   if (m64 < 0 || n64 < 0 || (m64 > 0 && !x) || (n64 > 0 && !y)) return fail(ctx, SA_ERR_ARG, "bad sequence arguments");
   if (m64 > 0x7ff00000LL || n64 > 0x7ff00000LL) return fail(ctx, SA_ERR_ARG, "sequence longer than int32 indexing (reference Q7)");
   const int m = (int)m64, n = (int)n64;
+  // SA_TIMING=1: host-side stages of the call on stderr (where the time outside the kernels goes)
+  static const bool timing = getenv("SA_TIMING") != nullptr;
+  const auto tp0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (timing) fprintf(stderr, "[sa_timing] %-28s %8.3f ms since call\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
+  };
   int rc = check_scoring(ctx, kind, sc, m, n);
   if (rc) return rc;
   if (kind != KIND_LCS && first_invalid_pair(x, m, y, n, sc->idx256, &out->bad_x, &out->bad_y))
@@ -1161,8 +1177,13 @@ int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t
   if (dump && ((double)m + 1) * ((double)n + 1) > 1.5e9)
     return fail(ctx, SA_ERR_NOMEM, "SA_FLAG_KEEP_DP: a %d x %d int32 matrix is beyond the 6 GB dump limit", m + 1, n + 1);
 
+  lap("checks, residue scan");
+  // borders: closed forms written on the device when nothing else needs the host's chains (fill_impl)
+  const bool integral = kind != KIND_NW || (sc->gap_open == std::floor(sc->gap_open) && sc->gap_extend == std::floor(sc->gap_extend));
+  const bool dev_borders = ctx->persist && !dump && m > 0 && n > 0 && integral;
   std::vector<int> rowb, colb;
-  border_chains(kind, m, n, sc, rowb, colb);
+  if (!dev_borders) border_chains(kind, m, n, sc, rowb, colb);
+  lap("border chains");
   if (dump) {
     out->dp = (int32_t*)calloc(((size_t)m + 1) * ((size_t)n + 1), 4);
     if (!out->dp) return fail(ctx, SA_ERR_NOMEM, "host malloc of the dp matrix failed");
@@ -1173,8 +1194,10 @@ int run_pair(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const uint8_t
     bool bits = false;
     if (kind == KIND_LCS && (rc = lcs_bits_fill(ctx, x, m, y, n, flags, out, &bits))) return rc;
     if (!bits && (rc = fill_impl(ctx, kind, x, m, y, n, sc, nullptr, flags, out, rowb, colb))) return rc;
+    lap("fill enqueued");
     if (dump) HIPCK(ctx, hipMemcpyAsync(out->dp, ctx->dpbuf.p, ((size_t)m + 1) * ((size_t)n + 1) * 4, hipMemcpyDeviceToHost, ctx->stream));
     if ((rc = traceback_impl(ctx, -1, -1, !(flags & SA_FLAG_NO_TRACEBACK), out))) return rc;
+    lap("traceback done (sync)");
     float t01 = 0, t12 = 0, t23 = 0;
     HIPCK(ctx, hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]));
     HIPCK(ctx, hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]));
