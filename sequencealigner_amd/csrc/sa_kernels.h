@@ -963,12 +963,15 @@ struct MoveEmitter {
 // holds row r's 32 two-bit codes (drift -16 first).  Per round: the diagonal run from (dcur, o) is the run of ones
 // in mask[o] from bit dcur (s_ff1 of its complement) and costs one addition to k (zero codes); then ONE gap move:
 // its code comes out of the row's scalar copy, goes into acc, and moves dcur / o.  Leaves -- with everything
-// consistent, the caller looks at k, dcur, o and the returned code -- when a word is full (k >= 32), the window is
-// done (dcur >= 64), an SW stop code (3) turns up, or the path drifted out of the window.  vcc is the 64-bit scratch pair
+// consistent, the caller looks at k, dcur, o and the returned code -- when the window is done (dcur >= 64), an SW
+// stop code (3) turns up, or the path drifted out of the window.  A full word of 32 moves is staged right here (out of
+// line: v_mov_b64 + ds_write_b64 at the LDS byte address `saddr`, which advances by 8): leaving the loop for it cost
+// two exits per window, each ~350 cycles of branches and compiled bookkeeping for a lone wave.  vcc is the 64-bit scratch pair
 // (inline asm cannot name the halves of a 64-bit operand).
 __device__ __forceinline__ uint32_t walk_rounds(const bool tagged, const uint32_t dm_lo, const uint32_t dm_hi, const uint32_t Flo,
-                                                const uint32_t Fhi, int& dcur, int& o, int& k, unsigned long long& acc) {
+                                                const uint32_t Fhi, int& dcur, int& o, int& k, unsigned long long& acc, uint32_t& saddr) {
   uint32_t c = 0, t0, t1, L;
+  unsigned long long wtmp;
   if (tagged) {
     asm volatile(
         "Ltop_%=:\n\t"
@@ -983,7 +986,8 @@ __device__ __forceinline__ uint32_t walk_rounds(const bool tagged, const uint32_
         "s_add_i32 %[k], %[k], %[L]\n\t"
         "s_add_i32 %[d], %[d], %[L]\n\t"
         "s_cmp_ge_i32 %[k], 32\n\t"
-        "s_cbranch_scc1 Lout_%=\n\t"
+        "s_cbranch_scc1 Lword_%=\n\t"
+        "Lback_%=:\n\t"
         "s_cmp_ge_i32 %[d], 64\n\t"
         "s_cbranch_scc1 Lout_%=\n\t"
         "v_readlane_b32 vcc_hi, %[fhi], %[d]\n\t"
@@ -1008,10 +1012,21 @@ __device__ __forceinline__ uint32_t walk_rounds(const bool tagged, const uint32_
         "s_add_i32 %[t0], %[o], 16\n\t"
         "s_cmp_lt_u32 %[t0], 32\n\t"
         "s_cbranch_scc1 Ltop_%=\n\t"
+        "s_branch Lout_%=\n\t"
+        "Lword_%=:\n\t"                       // a word of 32 moves is full: stage it, start the next
+        "v_mov_b64 %[wtmp], %[acc]\n\t"
+        "ds_write_b64 %[saddr], %[wtmp]\n\t"
+        "v_add_u32 %[saddr], 8, %[saddr]\n\t"
+        "s_mov_b64 %[acc], 0\n\t"
+        "s_sub_i32 %[k], %[k], 32\n\t"
+        "s_cmp_ge_i32 %[k], 32\n\t"
+        "s_cbranch_scc1 Lword_%=\n\t"
+        "s_branch Lback_%=\n\t"
         "Lout_%=:\n\t"
-        : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [c] "+s"(c), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L)
+        : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [c] "+s"(c), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L),
+          [saddr] "+v"(saddr), [wtmp] "=&v"(wtmp)
         : [dmlo] "v"(dm_lo), [dmhi] "v"(dm_hi), [flo] "v"(Flo), [fhi] "v"(Fhi)
-        : "scc", "vcc");
+        : "scc", "vcc", "memory");
   } else {  // LCS: codes 3 diagonal, 2 up, 1 left are the ops themselves; there is no stop code
     asm volatile(
         "Ltop_%=:\n\t"
@@ -1026,7 +1041,8 @@ __device__ __forceinline__ uint32_t walk_rounds(const bool tagged, const uint32_
         "s_add_i32 %[k], %[k], %[L]\n\t"
         "s_add_i32 %[d], %[d], %[L]\n\t"
         "s_cmp_ge_i32 %[k], 32\n\t"
-        "s_cbranch_scc1 Lout_%=\n\t"
+        "s_cbranch_scc1 Lword_%=\n\t"
+        "Lback_%=:\n\t"
         "s_cmp_ge_i32 %[d], 64\n\t"
         "s_cbranch_scc1 Lout_%=\n\t"
         "v_readlane_b32 vcc_hi, %[fhi], %[d]\n\t"
@@ -1048,10 +1064,21 @@ __device__ __forceinline__ uint32_t walk_rounds(const bool tagged, const uint32_
         "s_add_i32 %[t0], %[o], 16\n\t"
         "s_cmp_lt_u32 %[t0], 32\n\t"
         "s_cbranch_scc1 Ltop_%=\n\t"
+        "s_branch Lout_%=\n\t"
+        "Lword_%=:\n\t"                       // a word of 32 moves is full: stage it, start the next
+        "v_mov_b64 %[wtmp], %[acc]\n\t"
+        "ds_write_b64 %[saddr], %[wtmp]\n\t"
+        "v_add_u32 %[saddr], 8, %[saddr]\n\t"
+        "s_mov_b64 %[acc], 0\n\t"
+        "s_sub_i32 %[k], %[k], 32\n\t"
+        "s_cmp_ge_i32 %[k], 32\n\t"
+        "s_cbranch_scc1 Lword_%=\n\t"
+        "s_branch Lback_%=\n\t"
         "Lout_%=:\n\t"
-        : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L)
+        : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L), [saddr] "+v"(saddr),
+          [wtmp] "=&v"(wtmp)
         : [dmlo] "v"(dm_lo), [dmhi] "v"(dm_hi), [flo] "v"(Flo), [fhi] "v"(Fhi)
-        : "scc", "vcc");
+        : "scc", "vcc", "memory");
   }
   return c;
 }
@@ -1119,8 +1146,9 @@ __device__ __forceinline__ BitsWindow load_bits_window(const TraceArgs& a, int i
 // column j0 - d + o = lane 79 - d + o of ca, or of cb when that is 64 or more (v_readlane takes the lane modulo 64).
 __device__ __forceinline__ void walk_rounds_bits(const uint32_t dm_lo, const uint32_t dm_hi, const uint32_t ca_lo, const uint32_t ca_hi,
                                                  const uint32_t cb_lo, const uint32_t cb_hi, int& dcur, int& o, int& k,
-                                                 unsigned long long& acc) {
+                                                 unsigned long long& acc, uint32_t& saddr) {
   uint32_t t0, t1, L;
+  unsigned long long wtmp;
   asm volatile(
       "Ltop_%=:\n\t"
       "s_add_i32 %[t0], %[o], 16\n\t"
@@ -1134,7 +1162,8 @@ __device__ __forceinline__ void walk_rounds_bits(const uint32_t dm_lo, const uin
       "s_add_i32 %[k], %[k], %[L]\n\t"
       "s_add_i32 %[d], %[d], %[L]\n\t"
       "s_cmp_ge_i32 %[k], 32\n\t"
-      "s_cbranch_scc1 Lout_%=\n\t"
+      "s_cbranch_scc1 Lword_%=\n\t"
+      "Lback_%=:\n\t"
       "s_cmp_ge_i32 %[d], 64\n\t"
       "s_cbranch_scc1 Lout_%=\n\t"
       "s_sub_i32 %[t0], 79, %[d]\n\t"
@@ -1163,10 +1192,21 @@ __device__ __forceinline__ void walk_rounds_bits(const uint32_t dm_lo, const uin
       "s_add_i32 %[t0], %[o], 16\n\t"
       "s_cmp_lt_u32 %[t0], 32\n\t"
       "s_cbranch_scc1 Ltop_%=\n\t"
+      "s_branch Lout_%=\n\t"
+      "Lword_%=:\n\t"                       // a word of 32 moves is full: stage it, start the next
+      "v_mov_b64 %[wtmp], %[acc]\n\t"
+      "ds_write_b64 %[saddr], %[wtmp]\n\t"
+      "v_add_u32 %[saddr], 8, %[saddr]\n\t"
+      "s_mov_b64 %[acc], 0\n\t"
+      "s_sub_i32 %[k], %[k], 32\n\t"
+      "s_cmp_ge_i32 %[k], 32\n\t"
+      "s_cbranch_scc1 Lword_%=\n\t"
+      "s_branch Lback_%=\n\t"
       "Lout_%=:\n\t"
-      : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L)
+      : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L), [saddr] "+v"(saddr),
+        [wtmp] "=&v"(wtmp)
       : [dmlo] "v"(dm_lo), [dmhi] "v"(dm_hi), [calo] "v"(ca_lo), [cahi] "v"(ca_hi), [cblo] "v"(cb_lo), [cbhi] "v"(cb_hi)
-      : "scc", "vcc");
+      : "scc", "vcc", "memory");
 }
 
 // BITS: the bit-vector LCS format above instead of 2-bit codes (whole matrix only: no bands, no stripes)
@@ -1292,17 +1332,21 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
       int dcur = 0;
       unsigned long long acc = em.acc;  // the emitter's state in scalars of our own for the duration of the window
       int k = em.k, staged = em.staged;
+      // LDS byte address of the next staged word (all lanes hold the same value and store the same word)
+      const uint32_t stage0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned long long*)stage;
+      uint32_t saddr = stage0 + 8u * (uint32_t)staged;
       while (true) {
         // One round = the diagonal run from (dcur, o), then one gap move; rounds follow each other inside the
         // assembly until something rare happens (see walk_rounds).  Written by hand because the compiled loop
         // took four taken branches per round, and a lone wave pays ~50 cycles of instruction fetch for each.
         uint32_t c = 0;
         if constexpr (BITS)
-          walk_rounds_bits(dm_lo, dm_hi, ca_lo, ca_hi, cb_lo, cb_hi, dcur, o, k, acc);
+          walk_rounds_bits(dm_lo, dm_hi, ca_lo, ca_hi, cb_lo, cb_hi, dcur, o, k, acc, saddr);
         else
-          c = walk_rounds(tagged, dm_lo, dm_hi, Flo, Fhi, dcur, o, k, acc);
-        while (k >= 32) {  // all lanes store the same word to the same place: no divergence
-          stage[staged++] = acc;
+          c = walk_rounds(tagged, dm_lo, dm_hi, Flo, Fhi, dcur, o, k, acc, saddr);
+        while (k >= 32) {  // the loop was left right after the move that filled a word
+          stage[((uint32_t)__builtin_amdgcn_readfirstlane((int)saddr) - stage0) >> 3] = acc;  // all lanes, same word, same place
+          saddr += 8;
           acc = 0;
           k -= 32;
         }
@@ -1313,6 +1357,7 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
         }
         if (o < -16 || o > 15) break;  // drifted out of the window: re-centre
       }
+      staged = (int)((uint32_t)__builtin_amdgcn_readfirstlane((int)saddr) - stage0) >> 3;
       em.acc = acc;
       em.k = k;
       em.staged = staged;
