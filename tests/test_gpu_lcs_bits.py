@@ -97,3 +97,18 @@ def test_bits_score_only_and_fallbacks(engine, oracle):
     g = engine.lcs(x[:300], y[:200], flags=sa.SA_FLAG_KEEP_DP)
     od = oracle.lcs(x[:300], y[:200], keep_dp=True)
     assert g.rows_per_lane != 32 and np.array_equal(g.dp, od.dp)
+
+
+def test_bits_waves_per_workgroup(engine, oracle):
+    """The strips of the bit-vector kernel are independent waves; how many share a workgroup changes nothing."""
+    rng = np.random.default_rng(3204)
+    x = rand_seq(rng, 9000, DNA)
+    y = mutate(rng, x, DNA, 0.1, 0.03, 0.03)
+    o = oracle.lcs(x, y)
+    try:
+        for wpb in (1, 2, 4, 0):
+            engine.set_option("lcs_bits_waves_per_block", wpb)
+            g = engine.lcs(x, y)
+            assert g.rows_per_lane == 32 and g.score == o.score and np.array_equal(g.ops, o.ops), wpb
+    finally:
+        engine.set_option("lcs_bits_waves_per_block", 0)
