@@ -974,14 +974,14 @@ __device__ __forceinline__ uint32_t walk_rounds(const bool tagged, const uint32_
   unsigned long long wtmp;
   if (tagged) {
     asm volatile(
-        "Ltop_%=:\n\t"
         "s_add_i32 %[t0], %[o], 16\n\t"
+        "Ltop_%=:\n\t"                      // t0 = o + 16 here, from above or from the bottom of the round
         "v_readlane_b32 vcc_hi, %[dmhi], %[t0]\n\t"
         "v_readlane_b32 vcc_lo, %[dmlo], %[t0]\n\t"
         "s_lshr_b64 vcc, vcc, %[d]\n\t"
         "s_not_b64 vcc, vcc\n\t"
         "s_ff1_i32_b64 %[L], vcc\n\t"
-        "s_sub_i32 %[t1], 64, %[d]\n\t"
+        "s_sub_i32 %[t1], 64, %[d]\n\t"     // d = 64 can arrive here (an up move out of the last row): the shift was by 0 then
         "s_min_u32 %[L], %[L], %[t1]\n\t"
         "s_add_i32 %[k], %[k], %[L]\n\t"
         "s_add_i32 %[d], %[d], %[L]\n\t"
@@ -997,17 +997,12 @@ __device__ __forceinline__ uint32_t walk_rounds(const bool tagged, const uint32_
         "s_and_b32 %[c], vcc_lo, 3\n\t"
         "s_cmp_eq_u32 %[c], 3\n\t"
         "s_cbranch_scc1 Lout_%=\n\t"
-        "s_sub_i32 %[t1], 2, %[c]\n\t"          // op: 1 left, 2 up
-        "s_lshl_b32 %[t0], %[k], 1\n\t"
-        "s_mov_b32 vcc_hi, 0\n\t"
-        "s_mov_b32 vcc_lo, %[t1]\n\t"
-        "s_lshl_b64 vcc, vcc, %[t0]\n\t"
-        "s_or_b64 %[acc], %[acc], vcc\n\t"
+        "s_sub_i32 %[t1], 1, %[c]\n\t"          // 1 for an up move (op 2, tag F = 0), 0 for a left move (op 1, tag E = 1)
+        "s_lshl1_add_u32 %[t0], %[k], %[t1]\n\t"
+        "s_bitset1_b64 %[acc], %[t0]\n\t"       // the op is one set bit of the move's two: 2k (left) or 2k + 1 (up)
         "s_add_i32 %[k], %[k], 1\n\t"
-        "s_lshr_b32 %[t1], %[t1], 1\n\t"        // 1 for an up move
         "s_add_i32 %[d], %[d], %[t1]\n\t"
-        "s_lshl_b32 %[t1], %[t1], 1\n\t"
-        "s_add_i32 %[o], %[o], %[t1]\n\t"
+        "s_lshl1_add_u32 %[o], %[t1], %[o]\n\t"
         "s_add_i32 %[o], %[o], -1\n\t"
         "s_add_i32 %[t0], %[o], 16\n\t"
         "s_cmp_lt_u32 %[t0], 32\n\t"
@@ -1029,14 +1024,14 @@ __device__ __forceinline__ uint32_t walk_rounds(const bool tagged, const uint32_
         : "scc", "vcc", "memory");
   } else {  // LCS: codes 3 diagonal, 2 up, 1 left are the ops themselves; there is no stop code
     asm volatile(
-        "Ltop_%=:\n\t"
         "s_add_i32 %[t0], %[o], 16\n\t"
+        "Ltop_%=:\n\t"                      // t0 = o + 16 here, from above or from the bottom of the round
         "v_readlane_b32 vcc_hi, %[dmhi], %[t0]\n\t"
         "v_readlane_b32 vcc_lo, %[dmlo], %[t0]\n\t"
         "s_lshr_b64 vcc, vcc, %[d]\n\t"
         "s_not_b64 vcc, vcc\n\t"
         "s_ff1_i32_b64 %[L], vcc\n\t"
-        "s_sub_i32 %[t1], 64, %[d]\n\t"
+        "s_sub_i32 %[t1], 64, %[d]\n\t"     // d = 64 can arrive here (an up move out of the last row): the shift was by 0 then
         "s_min_u32 %[L], %[L], %[t1]\n\t"
         "s_add_i32 %[k], %[k], %[L]\n\t"
         "s_add_i32 %[d], %[d], %[L]\n\t"
@@ -1049,17 +1044,12 @@ __device__ __forceinline__ uint32_t walk_rounds(const bool tagged, const uint32_
         "v_readlane_b32 vcc_lo, %[flo], %[d]\n\t"
         "s_lshl_b32 %[t0], %[t0], 1\n\t"
         "s_lshr_b64 vcc, vcc, %[t0]\n\t"
-        "s_and_b32 %[t1], vcc_lo, 3\n\t"          // op: 1 left, 2 up
-        "s_lshl_b32 %[t0], %[k], 1\n\t"
-        "s_mov_b32 vcc_hi, 0\n\t"
-        "s_mov_b32 vcc_lo, %[t1]\n\t"
-        "s_lshl_b64 vcc, vcc, %[t0]\n\t"
-        "s_or_b64 %[acc], %[acc], vcc\n\t"
+        "s_bfe_u32 %[t1], vcc_lo, 0x10001\n\t"   // bit 1 of the code (1 left, 2 up): 1 for an up move
+        "s_lshl1_add_u32 %[t0], %[k], %[t1]\n\t"
+        "s_bitset1_b64 %[acc], %[t0]\n\t"
         "s_add_i32 %[k], %[k], 1\n\t"
-        "s_lshr_b32 %[t1], %[t1], 1\n\t"
         "s_add_i32 %[d], %[d], %[t1]\n\t"
-        "s_lshl_b32 %[t1], %[t1], 1\n\t"
-        "s_add_i32 %[o], %[o], %[t1]\n\t"
+        "s_lshl1_add_u32 %[o], %[t1], %[o]\n\t"
         "s_add_i32 %[o], %[o], -1\n\t"
         "s_add_i32 %[t0], %[o], 16\n\t"
         "s_cmp_lt_u32 %[t0], 32\n\t"
@@ -1150,8 +1140,8 @@ __device__ __forceinline__ void walk_rounds_bits(const uint32_t dm_lo, const uin
   uint32_t t0, t1, L;
   unsigned long long wtmp;
   asm volatile(
-      "Ltop_%=:\n\t"
       "s_add_i32 %[t0], %[o], 16\n\t"
+      "Ltop_%=:\n\t"
       "v_readlane_b32 vcc_hi, %[dmhi], %[t0]\n\t"
       "v_readlane_b32 vcc_lo, %[dmlo], %[t0]\n\t"
       "s_lshr_b64 vcc, vcc, %[d]\n\t"
@@ -1176,18 +1166,12 @@ __device__ __forceinline__ void walk_rounds_bits(const uint32_t dm_lo, const uin
       "s_cselect_b32 vcc_lo, vcc_lo, %[t1]\n\t"
       "s_cselect_b32 vcc_hi, vcc_hi, %[L]\n\t"
       "s_lshr_b64 vcc, vcc, %[d]\n\t"
-      "s_and_b32 %[t1], vcc_lo, 1\n\t"
-      "s_add_i32 %[t1], %[t1], 1\n\t"          // op: 1 left (bit clear), 2 up (bit set)
-      "s_lshl_b32 %[t0], %[k], 1\n\t"
-      "s_mov_b32 vcc_hi, 0\n\t"
-      "s_mov_b32 vcc_lo, %[t1]\n\t"
-      "s_lshl_b64 vcc, vcc, %[t0]\n\t"
-      "s_or_b64 %[acc], %[acc], vcc\n\t"
+      "s_and_b32 %[t1], vcc_lo, 1\n\t"          // set: up (op 2), clear: left (op 1)
+      "s_lshl1_add_u32 %[t0], %[k], %[t1]\n\t"
+      "s_bitset1_b64 %[acc], %[t0]\n\t"
       "s_add_i32 %[k], %[k], 1\n\t"
-      "s_lshr_b32 %[t1], %[t1], 1\n\t"
       "s_add_i32 %[d], %[d], %[t1]\n\t"
-      "s_lshl_b32 %[t1], %[t1], 1\n\t"
-      "s_add_i32 %[o], %[o], %[t1]\n\t"
+      "s_lshl1_add_u32 %[o], %[t1], %[o]\n\t"
       "s_add_i32 %[o], %[o], -1\n\t"
       "s_add_i32 %[t0], %[o], 16\n\t"
       "s_cmp_lt_u32 %[t0], 32\n\t"
