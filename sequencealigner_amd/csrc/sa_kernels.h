@@ -30,6 +30,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <utility>
 #include <climits>
 #include <cstdint>
 
@@ -1077,6 +1078,30 @@ __device__ __forceinline__ uint32_t walk_rounds(const bool tagged, const uint32_
 // a VALU instruction that writes a scalar register (the compare) and a VALU instruction that reads it as an operand
 // (v_writelane): the compiler inserts them in its own code but does not look inside inline assembly -- as two
 // statements the first v_writelane could see the PREVIOUS compare's mask, depending on what got scheduled between.
+// The same with a = byte B of a dword (SDWA selects it inside the compare: no extraction)
+template <int B>
+__device__ __forceinline__ void ballot_eq_byte_to_lane(uint32_t& lo, uint32_t& hi, uint32_t word, uint32_t b, const int q) {
+  static_assert(B >= 0 && B < 4, "byte of a dword");
+#define SA_BALLOT_BYTE(SEL)                                                  \
+  asm("v_cmp_eq_u32_sdwa vcc, %2, %3 src0_sel:" SEL " src1_sel:DWORD\n\t"     \
+      "s_nop 1\n\t"                                                          \
+      "v_writelane_b32 %0, vcc_lo, %4\n\t"                                   \
+      "v_writelane_b32 %1, vcc_hi, %4"                                        \
+      : "+v"(lo), "+v"(hi)                                                   \
+      : "v"(word), "v"(b), "n"(q)                                            \
+      : "vcc")
+  if constexpr (B == 0) SA_BALLOT_BYTE("BYTE_0");
+  else if constexpr (B == 1) SA_BALLOT_BYTE("BYTE_1");
+  else if constexpr (B == 2) SA_BALLOT_BYTE("BYTE_2");
+  else SA_BALLOT_BYTE("BYTE_3");
+#undef SA_BALLOT_BYTE
+}
+// lane q of (lo, hi) <- "byte q of the lane's 32 bytes yv[0..7] equals b", q = 0..31
+template <int... Q>
+__device__ __forceinline__ void ballot_bytes_to_lanes(uint32_t& lo, uint32_t& hi, const uint32_t (&yv)[8], uint32_t b,
+                                                      std::integer_sequence<int, Q...>) {
+  (ballot_eq_byte_to_lane<(Q & 3)>(lo, hi, yv[Q >> 2], b, Q), ...);
+}
 __device__ __forceinline__ void ballot_eq_to_lane(uint32_t& lo, uint32_t& hi, uint32_t a, uint32_t b, const int q) {
   asm("v_cmp_eq_u32_e64 vcc, %2, %3\n\t"
       "s_nop 1\n\t"
@@ -1097,8 +1122,11 @@ constexpr int kBitsStripPad = 0;  // dwords between the records of consecutive s
 constexpr int kBitsSkew = 2;  // the fill's skew (sa_lcsbits.hip): lane l meets column c at step c + kBitsSkew * l
 __device__ __forceinline__ uint32_t bits_word(const TraceArgs& a, int g, int c) {
   const int sidx = g >> 6, l = g & 63;
-  const int t = c + kBitsSkew * l;
-  return a.trace[(size_t)sidx * ((size_t)a.W * 64 + kBitsStripPad) + (size_t)(t & ~3) * 64 + l * 4 + (t & 3)];
+  // the strip's base is scalar in the window loads (g is wave-uniform there); inside a strip 32-bit dword indices do
+  // (W * 64 < 2^32: the host refuses longer targets), so the loads are scalar base + 32-bit lane offset
+  const uint32_t* sb = a.trace + (size_t)sidx * ((size_t)a.W * 64 + kBitsStripPad);
+  const uint32_t t = (uint32_t)(c + kBitsSkew * l);
+  return sb[((t & ~3u) << 6) + (uint32_t)(l * 4) + (t & 3u)];
 }
 // op code (0 diagonal, 1 left, 2 up) of cell (i, j), 1-based
 __device__ __forceinline__ uint32_t bits_code(const TraceArgs& a, int i, int j) {
@@ -1201,7 +1229,7 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
   // at the top of the next round (vmcnt counts loads and stores together, in order) waits for
   // nothing else -- the prefetch really overlaps the walk through the current window.
   __shared__ unsigned long long stage[kTraceStageWords];
-  __shared__ uint8_t ywin[BITS ? 128 : 8];  // BITS: the target symbols of the window's 96 columns
+  __shared__ __attribute__((aligned(16))) uint8_t ywin[BITS ? 128 : 16];  // BITS: the target symbols of the window's 96 columns
   const int d = threadIdx.x;
   const bool tagged = a.kind != KIND_LCS;
   int lgK = 0;
@@ -1289,8 +1317,17 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
         ywin[d] = (uint8_t)w.ya;
         ywin[64 + d] = (uint8_t)w.yb;
         wave_lds_fence();
+        // the lane's 32 symbols, entries 63 - d .. 94 - d: nine aligned dwords, realigned by bytes; the compares then
+        // pick their byte themselves (one LDS round trip per window instead of 32 byte reads with a wait each)
+        const uint32_t* yw32 = reinterpret_cast<const uint32_t*>(ywin);
+        const int yw0 = (63 - d) >> 2;
+        const uint32_t ysh = (uint32_t)(63 - d) & 3u;
+        uint32_t yr[9], yv[8];
 #pragma unroll
-        for (int q = 0; q < 32; ++q) ballot_eq_to_lane(dm_lo, dm_hi, (uint32_t)ywin[63 - d + q], w.xv, q);
+        for (int k = 0; k < 9; ++k) yr[k] = yw32[yw0 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) yv[k] = __builtin_amdgcn_alignbyte(yr[k + 1], yr[k], ysh);
+        ballot_bytes_to_lanes(dm_lo, dm_hi, yv, w.xv, std::make_integer_sequence<int, 32>{});
       } else {
       // The lane's 32 codes around its own cell of the entry diagonal, as one 64-bit value: the code
       // at drift o (-16..15) is bits [2(o+16), 2(o+16)+1] (two funnel shifts per window).

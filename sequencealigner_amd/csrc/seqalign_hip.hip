@@ -872,6 +872,7 @@ int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n,
     budget = (size_t)((double)total_b * 0.88);
   }
   if (trace_bytes > budget) return SA_OK;
+  if ((size_t)Tend * 64 + kBitsStripPad >= ((size_t)1 << 32)) return SA_OK;  // the walker indexes a strip's record with 32 bits
   // Waves per workgroup: as few as still give every strip a wave in one round.  A CU sustains ~25 GB/s of record writes
   // (so does a plain fill: 6.9 TB/s over 256 CUs), and 489 strips as 123 workgroups of four waves use 123 CUs: 2.7 TB/s,
   // 47 ms at 1 Mb x 1 Mb; as 245 workgroups of two waves they use 245.
