@@ -137,6 +137,79 @@ def reference_baseline(x, y, kind, sample):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def bench_small_pairs(eng, no_cpu):
+    """BASELINE.json configs 1 and 2, the latency cases: dna1 x dna2 NW (8 416 x 719, EDNAFULL) and P00533 x P08581 SW
+    (1 210 x 1 390, EBLOSUM62).  Per case: one warm C-ABI call (wall and fill-kernel ms, median of 25 after 3 warm-up
+    calls); one COLD process of the drop-in CLI, start to result files written (what the reference's caller pays per
+    request: alignment_runner.py:176-191 starts one process per alignment) with the CLI's own time_ms; and the compiled
+    reference (oracle/_ref/aligner_ref) the same way where its binary is present.  main.cpp:1092-1093, 1268-1271."""
+    import re
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+
+    from sequencealigner_amd import host
+
+    inputs = ROOT / "tests" / "golden" / "inputs"
+    cli = ROOT / "sequencealigner_amd" / "aligner"
+    out = {}
+    for name, q, t, mode, choice, kind, stats_file in (("config1_nw_dna1_dna2", "dna1.fasta", "dna2.fasta", "dna", 1, "nw", "global_stats.json"),
+                                                      ("config2_sw_P00533_P08581", "P00533.fasta", "P08581.fasta", "protein", 2, "sw", "local_stats.json")):
+        if not (inputs / q).exists():
+            continue
+        _h1, x = host.read_fasta(inputs / q)
+        _h2, y = host.read_fasta(inputs / t)
+        fn = getattr(eng, kind)
+        walls, kerns, tbs = [], [], []
+        for k in range(28):
+            t0 = time.perf_counter()
+            r = fn(x, y, mode)
+            dt = (time.perf_counter() - t0) * 1e3
+            if k >= 3:
+                walls.append(dt)
+                kerns.append(r.kernel_fill_ms)
+                tbs.append(r.traceback_ms)
+        e = {"shape": f"{len(x)}x{len(y)}", "score": int(r.score), "rows_per_lane": r.rows_per_lane,
+             "warm_call_ms": round(statistics.median(walls), 3), "warm_fill_kernel_ms": round(statistics.median(kerns), 3),
+             "warm_traceback_plus_d2h_ms": round(statistics.median(tbs), 3), "warm_calls": len(walls)}
+
+        def cold(binary, env=None):
+            ws, tms = [], []
+            for _ in range(3):
+                d = tempfile.mkdtemp(prefix="sa_small_")
+                try:
+                    t0 = time.perf_counter()
+                    p = subprocess.run([str(binary), "--query", str(inputs / q), "--target", str(inputs / t), "--choice", str(choice),
+                                        "--mode", mode, "--outdir", d], capture_output=True, env=env, timeout=300)
+                    w = (time.perf_counter() - t0) * 1e3
+                    sf = Path(d) / stats_file
+                    if p.returncode != 0 or not sf.exists():
+                        return None
+                    m_ = re.search(r'"time_ms":\s*(\d+)', sf.read_text())
+                    ws.append(w)
+                    tms.append(int(m_.group(1)) if m_ else -1)
+                finally:
+                    shutil.rmtree(d, ignore_errors=True)
+            return {"process_wall_ms": round(min(ws), 1), "time_ms_field": int(statistics.median(tms)), "runs": len(ws)}
+
+        if cli.exists():
+            e["cold_cli"] = cold(cli)
+        if not no_cpu:
+            from oracle import pyoracle
+
+            if pyoracle.ref_binary() is not None:
+                env = dict(os.environ)
+                env["LD_LIBRARY_PATH"] = "/usr/lib/x86_64-linux-gnu:/opt/conda/lib"
+                e["reference_cpu"] = cold(pyoracle.ref_binary(), env)
+        out[name] = e
+    out["note"] = ("warm_call_ms: one sa_nw / sa_sw call through the C-ABI on a live ctx (host encoding, H2D, fill, traceback, D2H), median; "
+                   "cold_cli: one process of sequencealigner_amd/aligner from exec to exit, result files written (HIP start-up and sa_create "
+                   "included), best of 3; reference_cpu: oracle/_ref/aligner_ref (the unmodified reference, one core) the same way; "
+                   "time_ms_field: what each program writes into its stats JSON (fill + traceback only, main.cpp:736 -> :820)")
+    return out
+
+
 def bench_batch(args, rank, local_rank, world, dist, torch, workload=None, nested=False):
     """Config 5: independent protein pairs (300-1000 aa, BLOSUM62, -5/-1), SW score + end cell
     (--workload batch) or full local alignments (--workload batch-align: + direction codes, per-pair
@@ -293,6 +366,10 @@ def pmc_traffic(args, m, n, world, res):
     return json.loads(f.read_text())["derived"]["hbm_traffic_bytes_per_launch"]
 
 
+# what every rank reports about its own stripe in an N > 1 line (milliseconds per step, averaged over the timed steps)
+PER_RANK_KEYS = ("rank", "fill_ms", "fill_kernel_ms", "border_wait_ms", "traceback_ms", "rows_per_lane", "overlapped", "stripe_cols")
+
+
 def launch_check(args, rank, world):
     """`--launch-check`: no GPU work -- every rank joins a gloo group and reports; rank 0 prints which ranks it saw.
     What the CPU test of the launcher runs (tests/test_bench_launcher.py)."""
@@ -312,8 +389,10 @@ def launch_check(args, rank, world):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but {ranks} ranks joined")
     print(f"LAUNCH_CHECK rank {rank} of {world} pid {os.getpid()} GPU_MAX_HW_QUEUES={os.environ.get('GPU_MAX_HW_QUEUES')}", flush=True)
     if rank == 0:
+        # the keys a measured N > 1 line carries per rank (tests/test_bench_launcher.py pins them)
         print(json.dumps({"launch_check": True, "n_gpus": args.gpus, "rccl_ranks": ranks, "ranks_reported": seen,
-                          "backend": "gloo (launch check only; measurements use nccl = RCCL)"}), flush=True)
+                          "backend": "gloo (launch check only; measurements use nccl = RCCL)",
+                          "per_rank": [dict.fromkeys(PER_RANK_KEYS, 0) | {"rank": r} for r in seen]}), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -332,6 +411,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=40000)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="pair workload: leave the nested config-5 object out")
+    ap.add_argument("--no-small", action="store_true", help="pair workload: leave the nested configs-1-and-2 latency object out")
     ap.add_argument("--launch-check", action="store_true", help="start the ranks, let each report over gloo, no GPU work")
     ap.add_argument("--unrelated", action="store_true",
                     help="SURVEY 8d config 3 variant: independent uniform y (seed 5678) instead of the ~90 %% identity pair")
@@ -420,23 +500,38 @@ def main():
                 res = run()
             else:
                 raise
-    sync()
-    t0 = time.perf_counter()
-    kernel_ms = 0.0
-    tb_ms = 0.0
-    dev_ms = 0.0
-    launches = 0
-    cells_trace = cells_notrace = 0
-    for _ in range(args.steps):
-        res = run()
-        dev_ms += res.fill_ms + res.traceback_ms
-        kernel_ms += res.kernel_fill_ms
-        tb_ms += res.traceback_ms
-        launches += res.n_launches
-        cells_trace += res.cells_trace
-        cells_notrace += res.cells_notrace
-    sync()
-    dt = time.perf_counter() - t0
+    def timed_steps():
+        sync()
+        t0 = time.perf_counter()
+        acc = {"kernel_ms": 0.0, "tb_ms": 0.0, "dev_ms": 0.0, "fill_ms": 0.0, "wait_ms": 0.0, "launches": 0, "cells_trace": 0, "cells_notrace": 0}
+        res = None
+        for _ in range(args.steps):
+            res = run()
+            acc["dev_ms"] += res.fill_ms + res.traceback_ms
+            acc["fill_ms"] += res.fill_ms
+            acc["kernel_ms"] += res.kernel_fill_ms
+            acc["tb_ms"] += res.traceback_ms
+            acc["wait_ms"] += res.border_wait_ms
+            acc["launches"] += res.n_launches
+            acc["cells_trace"] += res.cells_trace
+            acc["cells_notrace"] += res.cells_notrace
+        sync()
+        return res, acc, time.perf_counter() - t0
+
+    try:
+        res, acc, dt = timed_steps()
+    except RuntimeError as e:
+        # The same failure inside the timed loop (every rank raises StripeError together, stripes.py): finish on the
+        # in-line schedule and say so, so that the line is always printed and can be read.
+        if world > 1 and runner.overlap and type(e).__name__ == "StripeError":
+            runner.overlap = False
+            schedule_note = f"overlapped schedule failed in a timed step ({e}); all steps re-timed on the in-line schedule"
+            res, acc, dt = timed_steps()
+        else:
+            raise
+    kernel_ms, tb_ms, dev_ms, launches = acc["kernel_ms"], acc["tb_ms"], acc["dev_ms"], acc["launches"]
+    cells_trace, cells_notrace = acc["cells_trace"], acc["cells_notrace"]
+    per_rank = None
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -448,6 +543,15 @@ def main():
         cc = torch.tensor([float(cells_trace), float(cells_notrace)], dtype=torch.float64, device="cuda")
         dist.all_reduce(cc, op=dist.ReduceOp.SUM)
         cells_trace, cells_notrace = int(cc[0].item()), int(cc[1].item())
+        # what every rank saw of its own stripe: a bad curve can be read off the record (who waited for whom)
+        stripe = res.extra.get("stripe", (0, 0)) if isinstance(res.extra, dict) else (0, 0)
+        mine = torch.tensor([float(rank), acc["fill_ms"] / args.steps, acc["kernel_ms"] / args.steps, acc["wait_ms"] / args.steps,
+                             acc["tb_ms"] / args.steps, float(res.rows_per_lane), 1.0 if res.extra.get("overlapped") else 0.0,
+                             float(stripe[1] - stripe[0])], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{k: (int(v) if k in ("rank", "rows_per_lane", "stripe_cols") else (bool(v) if k == "overlapped" else round(float(v), 3)))
+                     for k, v in zip(PER_RANK_KEYS, t.tolist())} for t in allr]
 
     line = None
     if rank == 0:
@@ -537,6 +641,12 @@ def main():
                         "HBM roof: a strip is ONE wave sweeping n columns in sequence, about 11 instructions per column step, and a lone wave "
                         "issues one instruction per 4+ cycles (DESIGN 3.1b); strips beyond the first add only the pipeline lag.",
             }
+        if per_rank is not None:
+            line["per_rank"] = per_rank
+            line["per_rank_note"] = ("ms per step on each rank: fill_ms = H2D + profile + stripe fill, fill_kernel_ms = the stripe's persistent launch "
+                                     "(includes the time it waits for its left neighbour), border_wait_ms = of that, what an average wave spent "
+                                     "polling for rows of the left border, traceback_ms = this stripe's walk + D2H; overlapped = borders crossed "
+                                     "under the running kernel (false: in-line schedule)")
         if schedule_note:
             line["config"]["schedule_note"] = schedule_note
         if not args.no_cpu and world == 1:
@@ -546,6 +656,13 @@ def main():
                 rb["port"] = {"value": cb["value"], "sample": cb["sample"]}
                 cb = rb
             line["cpu_baseline"] = cb
+
+    if world == 1 and args.workload == "pair" and not args.no_small and rank == 0:
+        # configs 1 and 2 of BASELINE.json: the latency cases, warm call / cold CLI process / the reference beside them
+        try:
+            line["small_pairs"] = bench_small_pairs(eng, args.no_cpu)
+        except Exception as e:  # noqa: BLE001 -- never lose the headline line to the side measurement
+            line["small_pairs"] = {"error": repr(e)}
 
     if not args.no_batch:
         # the other half of BASELINE.json's metric, same run: config 5 sharded over the same ranks.  The pair's

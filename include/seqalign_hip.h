@@ -87,6 +87,9 @@ typedef struct {
    * checkpoint pass).  A checkpointed call has cells_notrace = m*n and cells_trace = the recomputed cells;
    * its band launches are counted in fill_ms / kernel_fill_ms, not in traceback_ms. */
   int64_t cells_trace, cells_notrace;
+  /* sa_stripe_fill with stream_in: milliseconds an average wave of the persistent launch spent waiting for rows of
+   * the left border to arrive (summed over its strips; 0 on the first stripe and on the in-line schedule) */
+  float border_wait_ms;
 } sa_result;
 
 /* ---- lifetime ---- */
@@ -110,7 +113,9 @@ int sa_set_tuning(sa_ctx* ctx, int rows_per_lane, int tile_steps);
  * "lcs_bits" 0/1 (default 1: sa_lcs on a whole pair over at most 63 distinct bytes runs as bit-vector
  * arithmetic -- 32 rows per lane, sa_result.rows_per_lane = 32, one bit of traceback record per cell; same
  * results as the cell-by-cell kernels, which still serve stripes, checkpointed runs, dumps and larger alphabets),
- * "lcs_bits_waves_per_block" 0 (automatic) / 1 / 2 / 4 (measurements: how many strips share a workgroup there) */
+ * "lcs_bits_waves_per_block" 0 (automatic) / 1 / 2 / 4 (measurements: how many strips share a workgroup there),
+ * "max_workgroups" N (0 = as many as the GPU holds: a persistent launch uses at most N workgroups of four waves;
+ * tests use it to make small inputs take several rounds of strips per wave; same results) */
 int sa_set_option(sa_ctx* ctx, const char* name, int64_t value);
 
 /* The reference's two built-in scoring schemes with default penalties -5/-1
@@ -136,15 +141,21 @@ int sa_lcs(sa_ctx* ctx, const uint8_t* x, int64_t m, const uint8_t* y, int64_t n
  * (main.cpp:1099-1128) per pair.  Pair k is x = seqs[off_x[k] .. +len_x[k]),
  * y = seqs[off_y[k] .. +len_y[k]).  Outputs are caller-owned arrays of n_pairs.
  * A pair with an invalid residue gets score = INT32_MIN and the call returns
- * SA_ERR_INVALID_CODE after finishing the other pairs. */
+ * SA_ERR_INVALID_CODE after finishing the other pairs.
+ * Penalties: non-positive, and -- for this and the other many-pair entry points below -- small enough for the batch
+ * kernels' 4x-scaled int32 arithmetic over their 1024 x 3895 limits: (4921) x max(|gap_open| + 1, |gap_extend| + 1,
+ * max |sub|) <= 1.2e8, i.e. penalties down to about -24 000; beyond that the call returns SA_ERR_ARG (sa_sw / sa_nw
+ * take such a pair, one at a time). */
 int sa_sw_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x,
                 const int64_t* off_y, const int32_t* len_y, int64_t n_pairs,
                 const sa_scoring* sc, int32_t* score, int32_t* end_i, int32_t* end_j,
                 float* kernel_ms);
 
-/* sa_sw_batch for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
- * forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  Same inputs, outputs, kernels and results as sa_sw_batch,
- * but the call allocates nothing: no hipMalloc / hipFree / hipHostMalloc and no host containers.  Its device
+/* sa_sw_batch for callers that cannot allocate (tight serving loops, harnesses that forbid hipMalloc, code that runs
+ * while another thread captures a HIP graph).  NO COUNTERPART IN THE REFERENCE.  Same inputs, outputs, kernels and
+ * results as sa_sw_batch, but the call allocates nothing: no hipMalloc / hipFree / hipHostMalloc and no host
+ * containers.  It is NOT itself capturable: it copies the caller's pageable buffers in, synchronises the ctx stream
+ * and reads the results back before it returns.  Its device
  * scratch (sequence staging, pair descriptors, per-pair results, error flag, scoring tables) is one file-scope
  * `static __device__` array of SA_NOALLOC_MAX_SEQ_BYTES + 48 + 12 bytes per pair of SA_NOALLOC_MAX_PAIRS + 2 KiB
  * (33 MiB) that every GPU the library runs on holds until the process ends; sa_create() looks its address up once per device and pins the
@@ -153,7 +164,9 @@ int sa_sw_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const in
  * in place), every pair must end within the first SA_NOALLOC_MAX_SEQ_BYTES of `seqs`; every pair must fit the batch
  * kernels (len_x <= 1024, len_y <= 3895: sa_sw_batch's single-pair fallback allocates and is not taken).
  * All calls on one GPU (from any ctx) share that GPU's array, which keeps the last call's contents (the call clears
- * what must start at zero): calls that overlap in time on one GPU race. */
+ * what must start at zero).  Calls of one process that overlap in time on one GPU do not race: the array has a busy
+ * flag per device and the second call returns SA_ERR_ARG ("scratch in use") at once; calls from different PROCESSES
+ * each have their own copy of the array. */
 #define SA_NOALLOC_MAX_PAIRS 16384
 #define SA_NOALLOC_MAX_SEQ_BYTES (32 << 20)
 int sa_sw_batch_noalloc(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x,

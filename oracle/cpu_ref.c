@@ -771,6 +771,102 @@ int orc_nw_banded(const uint8_t* x, int64_t m, const uint8_t* y, int64_t n, int 
   return rc;
 }
 
+/* Banded SW (main.cpp:1099-1128 fill + arg-max, :1182-1265 traceback) for sizes the full oracle cannot reach: row i
+ * covers columns [lo_i, hi_i] around c_i = i*n/m as in orc_nw_banded.  Cells outside the band read as S = E = F = 0,
+ * the floor every SW cell has anyway (main.cpp:968-970), i.e. a LOWER bound of their true values; in-band values are
+ * therefore lower bounds of the true ones and equal them wherever the best alignment ending in the cell stays inside
+ * the band.  The result (score, first row-major maximum, op list) is exact when the best local alignment and the
+ * cells that could tie with it lie inside the band -- true for the ~90 %-identity pairs it is used on; the walk reports
+ * through *touched_edge when it comes within a column of the band's edge.  One pointer per in-band cell, 2 bits
+ * (0 M, 1 E, 2 F, 3 X).  Validated against orc_sw in tests/test_oracle_golden.py at sizes both can run. */
+int orc_sw_banded(const uint8_t* x, int64_t m, const uint8_t* y, int64_t n, int mode, double go, double ge,
+                  int64_t band, orc_result* out, int* touched_edge) {
+  memset(out, 0, sizeof *out);
+  *touched_edge = 0;
+  scoring sc = {mode, go, ge, 0, 0, 0};
+  size_t bw = (size_t)(2 * band + 1);
+  size_t w = (size_t)n + 2;
+  uint64_t* T = (uint64_t*)calloc(((size_t)(m + 1) * bw + 31) / 32, sizeof(uint64_t));
+  int* rows = (int*)calloc(6 * w, sizeof(int));
+  if (!T || !rows) {
+    free(T);
+    free(rows);
+    return ORC_ERR_NOMEM;
+  }
+  int *pS = rows, *pE = rows + w, *pF = rows + 2 * w, *cS = rows + 3 * w, *cE = rows + 4 * w, *cF = rows + 5 * w;
+#define CTR(i) ((m) ? (int64_t)((__int128)(i) * n / m) : 0)
+#define LO(i) (CTR(i) - band < 0 ? 0 : CTR(i) - band)
+#define HI(i) (CTR(i) + band > n ? n : CTR(i) + band)
+  int best = 0;
+  int64_t bi = 0, bj = 0;
+  for (int64_t i = 1; i <= m && !sc.bad; ++i) {
+    int64_t lo = LO(i), hi = HI(i), plo = LO(i - 1), phi = HI(i - 1);
+    size_t base = (size_t)i * bw;
+    /* cells of the previous row outside ITS band, and the cell left of this row's band, read as zero */
+    for (int64_t j = phi + 1; j <= hi; ++j) pS[j] = pE[j] = pF[j] = 0;
+    for (int64_t j = (lo > 0 ? lo - 1 : 0); j < plo; ++j) pS[j] = pE[j] = pF[j] = 0;
+    if (lo > 0) cS[lo - 1] = cE[lo - 1] = cF[lo - 1] = 0;
+    for (int64_t j = lo; j <= hi; ++j) {
+      if (j == 0) { /* main.cpp:1104-1106 */
+        cS[0] = cE[0] = cF[0] = 0;
+        put2(T, base, 3);
+        continue;
+      }
+      sw_cell c = sw_cell_eval(&sc, pS[j - 1], pE[j - 1], pF[j - 1], cS[j - 1], cE[j - 1], pS[j], pF[j], x[i - 1], y[j - 1]);
+      if (sc.bad) break;
+      cS[j] = c.s;
+      cE[j] = c.e;
+      cF[j] = c.f;
+      put2(T, base + (size_t)(j - lo), c.ptr == 'M' ? 0u : ((c.ptr == 'E' || c.ptr == 'e') ? 1u : ((c.ptr == 'F' || c.ptr == 'f') ? 2u : 3u)));
+      if (c.s > best) { /* main.cpp:1124 */
+        best = c.s;
+        bi = i;
+        bj = j;
+      }
+    }
+    int* t;
+    t = pS, pS = cS, cS = t;
+    t = pE, pE = cE, cE = t;
+    t = pF, pF = cF, cF = t;
+  }
+  int rc = ORC_OK;
+  if (sc.bad) {
+    out->bad_x = sc.bad_x;
+    out->bad_y = sc.bad_y;
+    rc = ORC_ERR_INVALID_CODE;
+  } else {
+    out->score = best;
+    out->end_i = bi;
+    out->end_j = bj;
+    int64_t ci = bi, cj = bj, cap = 0;
+    while (ci > 0 && cj > 0) { /* main.cpp:1232-1259 */
+      int64_t lo = LO(ci), hi = HI(ci);
+      if ((lo > 0 && cj <= lo + 1) || (hi < n && cj >= hi - 1)) *touched_edge = 1;
+      if (cj < lo || cj > hi) {
+        *touched_edge = 2;
+        break;
+      }
+      unsigned c = get2(T, (size_t)ci * bw + (size_t)(cj - lo));
+      if (c == 3) break;
+      ops_push(&out->ops, &out->n_ops, &cap, (uint8_t)c);
+      if (c == 0)
+        --ci, --cj;
+      else if (c == 1)
+        --cj;
+      else
+        --ci;
+    }
+    out->start_i = ci;
+    out->start_j = cj;
+  }
+#undef CTR
+#undef LO
+#undef HI
+  free(T);
+  free(rows);
+  return rc;
+}
+
 /* Banded LCS (main.cpp:1575-1592 fill, :1602-1635 traceback) for sizes the full oracle cannot reach: row i
  * covers columns [lo_i, hi_i] around c_i = i*n/m as in orc_nw_banded.  L is monotone in i and in j, so a cell
  * outside the band is replaced by a LOWER bound of its true value: to the right of the previous row's band the

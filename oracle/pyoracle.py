@@ -86,6 +86,8 @@ class Oracle:
         L.orc_lcs_packed.argtypes = [p8, C.c_int64, p8, C.c_int64, C.POINTER(_Res)]
         L.orc_nw_banded.argtypes = [p8, C.c_int64, p8, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_int64,
                                     C.POINTER(_Res), C.POINTER(C.c_int)]
+        L.orc_sw_banded.argtypes = L.orc_nw_banded.argtypes
+        L.orc_sw_banded.restype = C.c_int
         L.orc_lcs_banded.argtypes = [p8, C.c_int64, p8, C.c_int64, C.c_int64, C.POINTER(_Res), C.POINTER(C.c_int)]
         L.orc_lcs_banded.restype = C.c_int
         L.orc_sw_score.argtypes = [p8, C.c_int64, p8, C.c_int64, C.c_int, C.c_double, C.c_double,
@@ -155,6 +157,14 @@ class Oracle:
         r = _Res()
         touched = C.c_int(0)
         rc = self.lib.orc_nw_banded(x.ctypes.data, len(x), y.ctypes.data, len(y), MODE[mode], go, ge, band,
+                                    C.byref(r), C.byref(touched))
+        return self._wrap(rc, r, len(x), len(y), False), touched.value
+
+    def sw_banded(self, x, y, band, mode="dna", go=-5.0, ge=-1.0):
+        x, y = _u8(x), _u8(y)
+        r = _Res()
+        touched = C.c_int(0)
+        rc = self.lib.orc_sw_banded(x.ctypes.data, len(x), y.ctypes.data, len(y), MODE[mode], go, ge, band,
                                     C.byref(r), C.byref(touched))
         return self._wrap(rc, r, len(x), len(y), False), touched.value
 

@@ -516,7 +516,7 @@ __global__ void __launch_bounds__(64) nw_batch_kernel(const BatchArgs a) {
 
 // One thread per pair: from (m, n) along the stored winners (M 2, E 1, F 0) to a border, then the
 // border walk of the reference (row 0: left moves, column 0: up moves; main.cpp:781-816).
-__global__ void nw_batch_traceback(const BatchArgs a) {
+static __global__ void nw_batch_traceback(const BatchArgs a) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= a.n_desc) return;
   const PairDesc pd = a.desc[q];
@@ -636,7 +636,7 @@ __global__ void __launch_bounds__(64) lcs_batch_kernel(const BatchArgs a) {
 
 // One thread per pair: lcs() traceback (main.cpp:1602-1635) over the stored codes (3 diagonal, 2 up,
 // 1 left), then the drains along the borders.
-__global__ void lcs_batch_traceback(const BatchArgs a) {
+static __global__ void lcs_batch_traceback(const BatchArgs a) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= a.n_desc) return;
   const PairDesc pd = a.desc[q];
@@ -683,7 +683,7 @@ inline long long batch_trace_dwords(int m, int n) {
 
 // One thread per pair follows the pointers from the pair's end cell to its 'X' cell
 // (main.cpp:1226-1262) and writes the moves, end -> start, four to a dword.
-__global__ void sw_batch_traceback(const BatchArgs a) {
+static __global__ void sw_batch_traceback(const BatchArgs a) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= a.n_desc) return;
   const PairDesc pd = a.desc[q];
@@ -725,7 +725,7 @@ __global__ void sw_batch_traceback(const BatchArgs a) {
 // be the maximum) and, as written, re-enters the match state after every diagonal move, so the
 // "alignment" is the ungapped diagonal through the best cell for as long as S > 0 -- and S > 0 is
 // exactly "the stored code is not the zero-cell tag 3".  One thread per window counts those steps.
-__global__ void sw_batch_diag_walk(const BatchArgs a) {
+static __global__ void sw_batch_diag_walk(const BatchArgs a) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= a.n_desc) return;
   const PairDesc pd = a.desc[q];

@@ -77,6 +77,7 @@ struct FillArgs {
   const int* rows_in;    // rows of `lb` that have arrived (raised by stripe_signal on the receive stream); null: all there
   int* chunk_done;       // [chunks] strips of border chunk k whose `rb` rows are written (stripe_wait polls it); null: no right neighbour
   int strips_per_chunk;
+  unsigned long long* wait_ticks;  // column stripes: 100 MHz ticks the strips of this launch spent waiting for rows of `lb` (summed over strips)
 };
 
 // Agent-scope relaxed atomic accesses (global_load / global_store .. sc1: the store writes through to L2, the
@@ -684,12 +685,16 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
     if (a.rows_in) {  // column stripes: the strip's rows of the left border must have arrived
       const int need = min(a.m, (s + 1) * 64 * K);
       int spins = 0;
-      while (ld_coherent(a.rows_in) < need) {
-        __builtin_amdgcn_s_sleep(16);
-        if (++spins > a.spin_limit || ((spins & 255) == 0 && ld_coherent(a.err) != 0)) {
-          dead = true;
-          break;
+      if (ld_coherent(a.rows_in) < need) {
+        const long long t0 = wall_clock64();
+        while (ld_coherent(a.rows_in) < need) {
+          __builtin_amdgcn_s_sleep(16);
+          if (++spins > a.spin_limit || ((spins & 255) == 0 && ld_coherent(a.err) != 0)) {
+            dead = true;
+            break;
+          }
         }
+        if (lane == 0 && a.wait_ticks) atomicAdd(a.wait_ticks, (unsigned long long)(wall_clock64() - t0));
       }
       if (dead) {
         if (lane == 0) st_coherent(a.err, 1);

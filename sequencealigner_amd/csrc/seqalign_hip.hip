@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
@@ -20,6 +21,7 @@
 #include "../../include/seqalign_hip.h"
 #include "sa_batch.h"
 #include "sa_kernels.h"
+#include "sa_launch.h"
 #include "sa_lcsbits.h"
 #include "sa_tables.h"
 
@@ -72,6 +74,8 @@ struct sa_ctx {
   int bits_wpb = 0; // bit-vector LCS: waves per workgroup, 0 = automatic (option "lcs_bits_waves_per_block", for measurements)
   int lcs_bits = 1; // 1: LCS of a whole pair over at most 63 distinct bytes runs as bit-vector arithmetic (sa_lcsbits.hip)
   int wps = 1;      // persistent kernel: waves per SIMD to launch
+  int max_wg = 0;   // persistent kernels: at most this many workgroups per launch (0: as many as the GPU holds); tests use it to
+                    // make small inputs take several rounds of tickets (ring-slot reuse, generations)
   int n_cu = 256;
   // cached device workspaces
   Buf xenc, yenc, prof, sub, colb, bot, state, trace, rowbest, small, ops;
@@ -179,6 +183,12 @@ constexpr double kHandoffLatencyUs = 2.9;  // record store (sc1) -> visible to t
 // is max(critical path over launches, total work / 1024 SIMDs).
 // n_upstream: columns owned by the stripes to the left (multi-GPU): this stripe cannot start
 // before its first strip has crossed them, at one column per step.
+// workgroups one persistent launch may use: one per CU and wave-per-SIMD, fewer when the option says so
+int persist_wg_cap(const sa_ctx* ctx) {
+  const int cap = ctx->n_cu * std::max(1, ctx->wps);
+  return ctx->max_wg > 0 ? std::min(cap, ctx->max_wg) : cap;
+}
+
 // rows per lane forced by sa_set_tuning; 16 exists only for the profile-driven persistent LCS, everything else takes 8 then
 int forced_K(const sa_ctx* ctx, bool has16 = false) { return (ctx->force_K == 16 && !has16) ? 8 : ctx->force_K; }
 
@@ -231,7 +241,7 @@ double pipeline_steps(double S, double waves, double n, double lag) {
 int choose_persist_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n, bool lprof = false, bool has16 = false) {
   if (ctx->force_K) return forced_K(ctx, has16);
   const double cell = kind == KIND_LCS ? (lprof ? 5.0 : 7.0) : (kind == KIND_SW ? 12.0 : 10.0);
-  const double waves = 4.0 * ctx->n_cu * std::max(1, ctx->wps);
+  const double waves = 4.0 * persist_wg_cap(ctx);
   double best = 1e300;
   int bestK = 1;
   for (int K : {1, 2, 4, 8, 16}) {
@@ -258,7 +268,7 @@ int choose_persist_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n, bool lpr
 int choose_stripe_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n, int64_t n_total, int64_t R, bool lprof = false) {
   const double cell = kind == KIND_LCS ? (lprof ? 5.0 : 7.0) : (kind == KIND_SW ? 12.0 : 10.0);
   const double step0 = 18.0;
-  const double waves = 4.0 * ctx->n_cu * std::max(1, ctx->wps);
+  const double waves = 4.0 * persist_wg_cap(ctx);
   double best = 1e300;
   int bestK = 0;
   for (int K : {1, 2, 4, 8}) {
@@ -275,82 +285,6 @@ int choose_stripe_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n, int64_t n
     }
   }
   return bestK ? bestK : 1;
-}
-
-template <int KIND>
-void launch_fill(int K, int fl, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a) {
-  // instantiated combinations: plain K in {1,2,4,8}; FRAC only with K=2; DUMP (+FRAC) only with K=1
-  if (fl == 0) {
-    switch (K) {
-      case 1: hipLaunchKernelGGL((fill_tile<KIND, 1, 0>), grid, dim3(64 * kWavesPerBlock), lds, st, a); break;
-      case 2: hipLaunchKernelGGL((fill_tile<KIND, 2, 0>), grid, dim3(64 * kWavesPerBlock), lds, st, a); break;
-      case 4: hipLaunchKernelGGL((fill_tile<KIND, 4, 0>), grid, dim3(64 * kWavesPerBlock), lds, st, a); break;
-      default: hipLaunchKernelGGL((fill_tile<KIND, 8, 0>), grid, dim3(64 * kWavesPerBlock), lds, st, a); break;
-    }
-  } else if (fl == FLAG_FRAC) {
-    hipLaunchKernelGGL((fill_tile<KIND, 2, FLAG_FRAC>), grid, dim3(64 * kWavesPerBlock), lds, st, a);
-  } else if (fl == FLAG_DUMP) {
-    hipLaunchKernelGGL((fill_tile<KIND, 1, FLAG_DUMP>), grid, dim3(64 * kWavesPerBlock), lds, st, a);
-  } else {
-    hipLaunchKernelGGL((fill_tile<KIND, 1, FLAG_DUMP | FLAG_FRAC>), grid, dim3(64 * kWavesPerBlock), lds, st, a);
-  }
-}
-
-// notrace: the FLAG_NOTRACE instances (score-only calls, the checkpoint pass): no codes are packed or stored
-// frac: NW with a fractional gap penalty (the FLAG_FRAC instances: one more VALU op per gap add; SW and LCS never need them)
-template <int KIND>
-void launch_persistent(int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a, bool notrace = false, bool lprof = false,
-                       bool frac = false) {
-  const dim3 blk(64 * kWavesPerBlock);
-  if constexpr (KIND == KIND_NW) {
-    if (frac) {
-      constexpr int F = FLAG_FRAC, FN = FLAG_FRAC | FLAG_NOTRACE;
-      switch (notrace ? -K : K) {
-        case 1: hipLaunchKernelGGL((fill_persistent<KIND, 1, F>), grid, blk, lds, st, a); break;
-        case 2: hipLaunchKernelGGL((fill_persistent<KIND, 2, F>), grid, blk, lds, st, a); break;
-        case 4: hipLaunchKernelGGL((fill_persistent<KIND, 4, F>), grid, blk, lds, st, a); break;
-        case 8: hipLaunchKernelGGL((fill_persistent<KIND, 8, F>), grid, blk, lds, st, a); break;
-        case -1: hipLaunchKernelGGL((fill_persistent<KIND, 1, FN>), grid, blk, lds, st, a); break;
-        case -2: hipLaunchKernelGGL((fill_persistent<KIND, 2, FN>), grid, blk, lds, st, a); break;
-        case -4: hipLaunchKernelGGL((fill_persistent<KIND, 4, FN>), grid, blk, lds, st, a); break;
-        default: hipLaunchKernelGGL((fill_persistent<KIND, 8, FN>), grid, blk, lds, st, a); break;
-      }
-      return;
-    }
-  }
-  if constexpr (KIND == KIND_LCS) {
-    if (lprof) {  // profile-driven LCS (small alphabets)
-      constexpr int F = FLAG_LPROF, FN = FLAG_LPROF | FLAG_NOTRACE;
-      switch (notrace ? -K : K) {
-        case 1: hipLaunchKernelGGL((fill_persistent<KIND, 1, F>), grid, blk, lds, st, a); break;
-        case 2: hipLaunchKernelGGL((fill_persistent<KIND, 2, F>), grid, blk, lds, st, a); break;
-        case 4: hipLaunchKernelGGL((fill_persistent<KIND, 4, F>), grid, blk, lds, st, a); break;
-        case 8: hipLaunchKernelGGL((fill_persistent<KIND, 8, F>), grid, blk, lds, st, a); break;
-        case 16: hipLaunchKernelGGL((fill_persistent<KIND, 16, F>), grid, blk, lds, st, a); break;
-        case -1: hipLaunchKernelGGL((fill_persistent<KIND, 1, FN>), grid, blk, lds, st, a); break;
-        case -2: hipLaunchKernelGGL((fill_persistent<KIND, 2, FN>), grid, blk, lds, st, a); break;
-        case -4: hipLaunchKernelGGL((fill_persistent<KIND, 4, FN>), grid, blk, lds, st, a); break;
-        case -16: hipLaunchKernelGGL((fill_persistent<KIND, 16, FN>), grid, blk, lds, st, a); break;
-        default: hipLaunchKernelGGL((fill_persistent<KIND, 8, FN>), grid, blk, lds, st, a); break;
-      }
-      return;
-    }
-  }
-  if (notrace) {
-    switch (K) {
-      case 1: hipLaunchKernelGGL((fill_persistent<KIND, 1, FLAG_NOTRACE>), grid, blk, lds, st, a); break;
-      case 2: hipLaunchKernelGGL((fill_persistent<KIND, 2, FLAG_NOTRACE>), grid, blk, lds, st, a); break;
-      case 4: hipLaunchKernelGGL((fill_persistent<KIND, 4, FLAG_NOTRACE>), grid, blk, lds, st, a); break;
-      default: hipLaunchKernelGGL((fill_persistent<KIND, 8, FLAG_NOTRACE>), grid, blk, lds, st, a); break;
-    }
-    return;
-  }
-  switch (K) {
-    case 1: hipLaunchKernelGGL((fill_persistent<KIND, 1, 0>), grid, blk, lds, st, a); break;
-    case 2: hipLaunchKernelGGL((fill_persistent<KIND, 2, 0>), grid, blk, lds, st, a); break;
-    case 4: hipLaunchKernelGGL((fill_persistent<KIND, 4, 0>), grid, blk, lds, st, a); break;
-    default: hipLaunchKernelGGL((fill_persistent<KIND, 8, 0>), grid, blk, lds, st, a); break;
-  }
 }
 
 void launch_profile(int K, hipStream_t st, const uint8_t* xidx, int m, const int8_t* sub, int alpha, int S,
@@ -533,17 +467,22 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
     HIPCK(ctx, hipMemGetInfo(&free_b, &total_b));
     budget = (size_t)((double)total_b * 0.88);
   }
-  const bool ckpt = !no_tb && !sd && ((size_t)S * strip_trace_bytes > budget || (ctx->force_band > 0 && persist));
+  // what the call holds besides the codes: the hand-off ring of a one-slab run (8 GB at 1 Mb x 1 Mb), the query profile
+  // and the O(m + n) buffers.  They come out of the same memory, so they count against the same budget.
+  const int grid_blocks = std::min((S + kWavesPerBlock - 1) / kWavesPerBlock, persist_wg_cap(ctx));
+  const size_t ring_slab = persist ? (size_t)std::min(S + 1, grid_blocks * kWavesPerBlock + 2) : 2;
+  const size_t fixed_bytes = 2 * ring_slab * NP * 4 + (size_t)S * alpha * 64 * PW * 4 + (size_t)S * NF * 64 * 4 + ((size_t)m + 1) * 8 +
+                             (kind == KIND_SW ? (size_t)2 * m * 4 : 0) + 2 * ((size_t)m + n) + rows_pad + (size_t)Tend + ((size_t)4 << 20);
+  const bool ckpt = !no_tb && !sd && ((size_t)S * strip_trace_bytes + fixed_bytes > budget || (ctx->force_band > 0 && persist));
   if (ckpt && !persist)
     return fail(ctx, SA_ERR_NOMEM, "%.1f GB of traceback codes exceed the budget and checkpointed recomputation needs the persistent "
                 "schedule (integral gaps, no matrix dump)", (double)S * strip_trace_bytes / 1e9);
   // slots of bottom rows: two for the launch-per-diagonal schedule; the persistent pipeline takes one per strip when
   // it keeps checkpoints or has few strips, else two more than the launch has waves (sa_kernels.h, ho_store)
-  const int grid_blocks = std::min((S + kWavesPerBlock - 1) / kWavesPerBlock, ctx->n_cu * std::max(1, ctx->wps));
   const int ring = !persist ? 2 : (ckpt ? S + 1 : std::min(S + 1, grid_blocks * kWavesPerBlock + 2));
   int band = S;
   if (ckpt) {
-    const size_t ck_bytes = (size_t)2 * ring * NP * 4;
+    const size_t ck_bytes = (size_t)2 * ring * NP * 4 + (fixed_bytes - 2 * ring_slab * NP * 4);  // checkpoint rows + the rest
     if (ck_bytes + strip_trace_bytes > budget) return fail(ctx, SA_ERR_NOMEM, "checkpoint rows (%.1f GB) do not fit the budget", ck_bytes / 1e9);
     band = (int)std::max<size_t>(1, std::min<size_t>((size_t)S, (budget - ck_bytes) / strip_trace_bytes));
     if (ctx->force_band > 0) band = std::min(band, ctx->force_band);
@@ -563,7 +502,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   if ((rc = ensure(ctx, ctx->bot, (size_t)2 * ring * NP * 4))) return rc;
   if ((rc = ensure(ctx, ctx->state, (size_t)S * NF * 64 * 4))) return rc;
   if ((rc = ensure(ctx, ctx->small, 256))) return rc;
-  const size_t pbuf_ints = (size_t)S + 64 + (size_t)n_chunks;
+  const size_t pbuf_ints = (size_t)S + 64 + (size_t)n_chunks;  // [0] ticket, [32] rows_in, [34..35] wait ticks, [64 + S ..] chunk_done
   if (persist && (rc = ensure(ctx, ctx->pbuf, pbuf_ints * 4))) return rc;
   if ((rc = ensure(ctx, ctx->ops, ops_bytes_offset(m, n) + ((size_t)m + n) / 4 + 1024))) return rc;  // one byte per move | packed moves
   if (kind != KIND_LCS || lprof) {
@@ -734,7 +673,10 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
 #endif
     a.err = (int*)ctx->small.p + 40;  // byte 160 of the small block, read back with the score
     a.spin_limit = 1 << 22;
-    if (striped && ev_in) a.rows_in = (int*)ctx->pbuf.p + 32;
+    if (striped && ev_in) {
+      a.rows_in = (int*)ctx->pbuf.p + 32;
+      a.wait_ticks = (unsigned long long*)((int*)ctx->pbuf.p + 34);
+    }
     if (striped && ev_out) {
       a.chunk_done = (int*)ctx->pbuf.p + 64 + S;
       a.strips_per_chunk = (int)(R / (64 * K));
@@ -749,12 +691,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
   if (persist) {
     const dim3 grid(grid_blocks);
-    if (kind == KIND_NW)
-      launch_persistent<KIND_NW>(K, grid, lds, st, a, ckpt || no_tb, false, (fl & FLAG_FRAC) != 0);
-    else if (kind == KIND_SW)
-      launch_persistent<KIND_SW>(K, grid, lds, st, a, ckpt || no_tb);
-    else
-      launch_persistent<KIND_LCS>(K, grid, lds, st, a, ckpt || no_tb, lprof);
+    launch_persistent_kind(kind, K, grid, lds, st, a, ckpt || no_tb, lprof, kind == KIND_NW && (fl & FLAG_FRAC) != 0);
     launches = 1;
     // border hand-offs, all enqueued now and resolved on the device while the fill runs
     for (int64_t k = 0; k < n_chunks && (a.rows_in || a.chunk_done); ++k) {
@@ -784,12 +721,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
     a.s_lo = slo;
     a.s_hi = shi;
     const dim3 grid((shi - slo + kWavesPerBlock) / kWavesPerBlock);
-    if (kind == KIND_NW)
-      launch_fill<KIND_NW>(K, fl, grid, lds, st, a);
-    else if (kind == KIND_SW)
-      launch_fill<KIND_SW>(K, fl, grid, lds, st, a);
-    else
-      launch_fill<KIND_LCS>(K, fl & FLAG_DUMP, grid, lds, st, a);
+    launch_fill_kind(kind, K, kind == KIND_LCS ? (fl & FLAG_DUMP) : fl, grid, lds, st, a);
     ++launches;
     if (ev_out) {  // strips with f_hi(s) <= d are complete after this launch
       int done = slo;
@@ -871,16 +803,17 @@ int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n,
     HIPCK(ctx, hipMemGetInfo(&free_b, &total_b));
     budget = (size_t)((double)total_b * 0.88);
   }
-  if (trace_bytes > budget) return SA_OK;
   if ((size_t)Tend * 64 + kBitsStripPad >= ((size_t)1 << 32)) return SA_OK;  // the walker indexes a strip's record with 32 bits
   // Waves per workgroup: as few as still give every strip a wave in one round.  A CU sustains ~25 GB/s of record writes
   // (so does a plain fill: 6.9 TB/s over 256 CUs), and 489 strips as 123 workgroups of four waves use 123 CUs: 2.7 TB/s,
   // 47 ms at 1 Mb x 1 Mb; as 245 workgroups of two waves they use 245.
-  const int cap = ctx->n_cu * std::max(1, ctx->wps);
+  const int cap = persist_wg_cap(ctx);
   const int wpb = ctx->bits_wpb ? ctx->bits_wpb : (S <= 2 * cap ? 2 : kWavesPerBlock);  // (single-wave workgroups are not guaranteed a SIMD of their own)
   const int grid_blocks = std::min((S + wpb - 1) / wpb, cap);
   const int ring = std::min(S + 1, grid_blocks * wpb + 2);
   const size_t rows_pad = (size_t)S * kBitsStripRows;
+  // the record, the hand-off ring and the small buffers must fit the budget together; else the cell kernels (which checkpoint)
+  if (trace_bytes + (size_t)2 * ring * NP * 4 + (size_t)S * alpha * 64 * 4 + 2 * ((size_t)m + n) + rows_pad + (size_t)Tend + ((size_t)4 << 20) > budget) return SA_OK;
   int rc;
   {
     const size_t need_bot = (size_t)2 * ring * NP * 4;
@@ -998,14 +931,9 @@ int traceback_ckpt(sa_ctx* ctx, int start_i, int start_j, sa_result* out) {
     a.s_first = s_lo;
     a.s_last = s_hi;
     a.trace_s0 = s_lo;
-    const dim3 grid(std::min((s_hi - s_lo + 1 + kWavesPerBlock - 1) / kWavesPerBlock, ctx->n_cu * std::max(1, ctx->wps)));
+    const dim3 grid(std::min((s_hi - s_lo + 1 + kWavesPerBlock - 1) / kWavesPerBlock, persist_wg_cap(ctx)));
     HIPCK(ctx, hipEventRecord(ctx->ev[5], st));
-    if (kind == KIND_NW)
-      launch_persistent<KIND_NW>(K, grid, ctx->last.lds, st, a, false, false, a.fo != 0 || a.fe != 0);
-    else if (kind == KIND_SW)
-      launch_persistent<KIND_SW>(K, grid, ctx->last.lds, st, a);
-    else
-      launch_persistent<KIND_LCS>(K, grid, ctx->last.lds, st, a, false, ctx->last.lprof != 0);
+    launch_persistent_kind(kind, K, grid, ctx->last.lds, st, a, false, kind == KIND_LCS && ctx->last.lprof != 0, kind == KIND_NW && (a.fo != 0 || a.fe != 0));
     HIPCK(ctx, hipEventRecord(ctx->ev[6], st));
     ++out->n_launches;
     out->cells_trace += (int64_t)(std::min<int64_t>(m, (int64_t)(s_hi + 1) * 64 * K) - (int64_t)s_lo * 64 * K) * n;
@@ -1262,6 +1190,13 @@ int run_stripe_fill(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const 
     return fail(ctx, SA_ERR_HIP, "persistent stripe fill: a bounded wait (previous strip / left border / border send) expired");
   }
   const int h_score = h_small[0];
+  if (ctx->last.args.wait_ticks) {  // 100 MHz ticks summed over the strips -> ms per wave of the launch
+    unsigned long long ticks = 0;
+    HIPCK(ctx, hipMemcpy(&ticks, ctx->last.args.wait_ticks, 8, hipMemcpyDeviceToHost));
+    const int S = ctx->last.S;
+    const int waves = std::min(S, std::min((S + kWavesPerBlock - 1) / kWavesPerBlock, persist_wg_cap(ctx)) * kWavesPerBlock);
+    out->border_wait_ms = (float)((double)ticks / 1e5 / std::max(1, waves));
+  }
   float t01 = 0, t12 = 0;
   HIPCK(ctx, hipEventElapsedTime(&t01, ctx->ev[0], ctx->ev[1]));
   HIPCK(ctx, hipEventElapsedTime(&t12, ctx->ev[1], ctx->ev[2]));
@@ -1293,90 +1228,6 @@ int run_stripe_traceback(sa_ctx* ctx, int64_t start_i, int64_t start_j, sa_resul
   HIPCK(ctx, hipEventElapsedTime(&t23, ctx->ev[2], ctx->ev[3]));
   out->traceback_ms = t23;
   return SA_OK;
-}
-
-template <int K>
-void launch_batch(hipStream_t st, int count, int alpha, const BatchArgs& a, bool trace) {
-  if (trace)
-    hipLaunchKernelGGL((sw_batch_kernel<K, true>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha, a.ycap), st, a);
-  else
-    hipLaunchKernelGGL((sw_batch_kernel<K, false>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha, a.ycap), st, a);
-}
-
-template <int K>
-void launch_nw_batch(hipStream_t st, int count, int alpha, const BatchArgs& a) {
-  if (a.fo || a.fe)
-    hipLaunchKernelGGL((nw_batch_kernel<K, true>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha, a.ycap), st, a);
-  else
-    hipLaunchKernelGGL((nw_batch_kernel<K, false>), dim3(count), dim3(64), batch_lds_bytes<K>(alpha, a.ycap), st, a);
-}
-
-void launch_nw_batch_k(int K, hipStream_t st, int count, int alpha, const BatchArgs& a) {
-  switch (K) {
-    case 1: launch_nw_batch<1>(st, count, alpha, a); break;
-    case 2: launch_nw_batch<2>(st, count, alpha, a); break;
-    case 3: launch_nw_batch<3>(st, count, alpha, a); break;
-    case 4: launch_nw_batch<4>(st, count, alpha, a); break;
-    case 5: launch_nw_batch<5>(st, count, alpha, a); break;
-    case 6: launch_nw_batch<6>(st, count, alpha, a); break;
-    case 7: launch_nw_batch<7>(st, count, alpha, a); break;
-    case 8: launch_nw_batch<8>(st, count, alpha, a); break;
-    case 9: launch_nw_batch<9>(st, count, alpha, a); break;
-    case 10: launch_nw_batch<10>(st, count, alpha, a); break;
-    case 11: launch_nw_batch<11>(st, count, alpha, a); break;
-    case 12: launch_nw_batch<12>(st, count, alpha, a); break;
-    case 13: launch_nw_batch<13>(st, count, alpha, a); break;
-    case 14: launch_nw_batch<14>(st, count, alpha, a); break;
-    case 15: launch_nw_batch<15>(st, count, alpha, a); break;
-    default: launch_nw_batch<16>(st, count, alpha, a); break;
-  }
-}
-
-template <int K>
-void launch_lcs_batch(hipStream_t st, int count, const BatchArgs& a) {
-  hipLaunchKernelGGL((lcs_batch_kernel<K>), dim3(count), dim3(64), (size_t)a.ycap + 64, st, a);
-}
-
-void launch_lcs_batch_k(int K, hipStream_t st, int count, const BatchArgs& a) {
-  switch (K) {
-    case 1: launch_lcs_batch<1>(st, count, a); break;
-    case 2: launch_lcs_batch<2>(st, count, a); break;
-    case 3: launch_lcs_batch<3>(st, count, a); break;
-    case 4: launch_lcs_batch<4>(st, count, a); break;
-    case 5: launch_lcs_batch<5>(st, count, a); break;
-    case 6: launch_lcs_batch<6>(st, count, a); break;
-    case 7: launch_lcs_batch<7>(st, count, a); break;
-    case 8: launch_lcs_batch<8>(st, count, a); break;
-    case 9: launch_lcs_batch<9>(st, count, a); break;
-    case 10: launch_lcs_batch<10>(st, count, a); break;
-    case 11: launch_lcs_batch<11>(st, count, a); break;
-    case 12: launch_lcs_batch<12>(st, count, a); break;
-    case 13: launch_lcs_batch<13>(st, count, a); break;
-    case 14: launch_lcs_batch<14>(st, count, a); break;
-    case 15: launch_lcs_batch<15>(st, count, a); break;
-    default: launch_lcs_batch<16>(st, count, a); break;
-  }
-}
-
-void launch_batch_k(int K, hipStream_t st, int count, int alpha, const BatchArgs& a, bool trace = false) {
-  switch (K) {
-    case 1: launch_batch<1>(st, count, alpha, a, trace); break;
-    case 2: launch_batch<2>(st, count, alpha, a, trace); break;
-    case 3: launch_batch<3>(st, count, alpha, a, trace); break;
-    case 4: launch_batch<4>(st, count, alpha, a, trace); break;
-    case 5: launch_batch<5>(st, count, alpha, a, trace); break;
-    case 6: launch_batch<6>(st, count, alpha, a, trace); break;
-    case 7: launch_batch<7>(st, count, alpha, a, trace); break;
-    case 8: launch_batch<8>(st, count, alpha, a, trace); break;
-    case 9: launch_batch<9>(st, count, alpha, a, trace); break;
-    case 10: launch_batch<10>(st, count, alpha, a, trace); break;
-    case 11: launch_batch<11>(st, count, alpha, a, trace); break;
-    case 12: launch_batch<12>(st, count, alpha, a, trace); break;
-    case 13: launch_batch<13>(st, count, alpha, a, trace); break;
-    case 14: launch_batch<14>(st, count, alpha, a, trace); break;
-    case 15: launch_batch<15>(st, count, alpha, a, trace); break;
-    default: launch_batch<16>(st, count, alpha, a, trace); break;
-  }
 }
 
 // Host op pools of sa_sw_batch_align: page-locked (the 1.3 GB of moves of a million pairs come back at
@@ -1665,13 +1516,13 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
         a.desc = (const PairDesc*)ctx->b_desc.p + ch.lo;
         a.n_desc = (int)(ch.hi - ch.lo);
         if (lcs)
-          hipLaunchKernelGGL(lcs_batch_traceback, dim3((a.n_desc + 63) / 64), dim3(64), 0, st, a);
+          launch_batch_tracebacks(2, st, a);
         else if (al->kind == KIND_NW)
-          hipLaunchKernelGGL(nw_batch_traceback, dim3((a.n_desc + 63) / 64), dim3(64), 0, st, a);
+          launch_batch_tracebacks(1, st, a);
         else if (al->diag_only)
-          hipLaunchKernelGGL(sw_batch_diag_walk, dim3((a.n_desc + 63) / 64), dim3(64), 0, st, a);
+          launch_batch_tracebacks(3, st, a);
         else
-          hipLaunchKernelGGL(sw_batch_traceback, dim3((a.n_desc + 63) / 64), dim3(64), 0, st, a);
+          launch_batch_tracebacks(0, st, a);
       }
       HIPCK(ctx, hipGetLastError());
       HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
@@ -1779,6 +1630,19 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
 // Device address of `scratch` on the CURRENT device, looked up once per device.
 std::mutex g_na_mu;
 unsigned char* g_na_ptr[64] = {nullptr};
+// Every ctx and thread of the process shares a device's one array: a call holds this flag from its first write to the
+// array until its results are on the host, and a second call arriving meanwhile is refused, not interleaved.
+std::atomic<int> g_na_busy[64];
+struct NaBusy {
+  int dev;
+  bool held;
+  explicit NaBusy(int d) : dev(d), held(g_na_busy[d].exchange(1, std::memory_order_acquire) == 0) {}
+  ~NaBusy() {
+    if (held) g_na_busy[dev].store(0, std::memory_order_release);
+  }
+  NaBusy(const NaBusy&) = delete;
+  NaBusy& operator=(const NaBusy&) = delete;
+};
 hipError_t na_scratch_for_device(int dev, unsigned char** out) {
   *out = nullptr;
   if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
@@ -1818,6 +1682,8 @@ int run_batch_noalloc(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, co
   HIPCK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int alpha = sc->alpha;
+  const NaBusy busy(ctx->device);  // released on every return path below
+  if (!busy.held) return fail(ctx, SA_ERR_ARG, "sa_sw_batch_noalloc: scratch in use (another call on GPU %d has not returned yet)", ctx->device);
 
   // counting sort by rows per lane K = ceil(m / 64), big pairs first, straight into the pinned staging block
   int group_count[18] = {0}, group_nmax[18] = {0}, group_start[18] = {0}, cur[18];
@@ -2007,6 +1873,9 @@ int sa_set_option(sa_ctx* c, const char* name, int64_t value) {
   } else if (!strcmp(name, "batch_trace_budget_mb")) {
     if (value < 1) return fail(c, SA_ERR_ARG, "batch_trace_budget_mb must be positive");
     c->batch_trace_budget = (size_t)value << 20;
+  } else if (!strcmp(name, "max_workgroups")) {  // 0: as many as the GPU holds
+    if (value < 0) return fail(c, SA_ERR_ARG, "max_workgroups must be >= 0");
+    c->max_wg = (int)std::min<int64_t>(value, 1 << 20);
   } else if (!strcmp(name, "waves_per_simd")) {
     if (value < 1 || value > 4) return fail(c, SA_ERR_ARG, "waves_per_simd must be 1..4");
     c->wps = (int)value;

@@ -67,6 +67,7 @@ class _Result(C.Structure):
         ("tile_steps", C.c_int32),
         ("cells_trace", C.c_int64),
         ("cells_notrace", C.c_int64),
+        ("border_wait_ms", C.c_float),
     ]
 
 
@@ -107,6 +108,7 @@ class AlignResult:
     tile_steps: int = 0
     cells_trace: int = 0
     cells_notrace: int = 0
+    border_wait_ms: float = 0.0
     extra: dict = field(default_factory=dict)
 
 
@@ -234,7 +236,7 @@ class Engine:
             dp = np.ctypeslib.as_array(r.dp, shape=(m + 1, n + 1)).copy()
         out = AlignResult(int(r.score), (int(r.end_i), int(r.end_j)), (int(r.start_i), int(r.start_j)), ops, dp,
                           r.fill_ms, r.traceback_ms, r.kernel_fill_ms, r.n_launches, r.rows_per_lane, r.tile_steps,
-                          int(r.cells_trace), int(r.cells_notrace))
+                          int(r.cells_trace), int(r.cells_notrace), float(r.border_wait_ms))
         self.lib.sa_free_result(C.byref(r))
         return out
 

@@ -225,7 +225,7 @@ class StripedAligner:
             raise StripeError(f"rank {g}: {failure}" if failure is not None else f"rank {g}: another rank's stripe fill failed")
 
         if kind == "sw":
-            return self._finish_sw(res, m, n, c0, ng, first)
+            return self._finish_sw(res, m, n, c0, ng, first, overlapped)
 
         # traceback, right to left: (exit row) travels g+1 -> g
         if last:
@@ -260,7 +260,8 @@ class StripedAligner:
         out.fill_ms, out.kernel_fill_ms, out.traceback_ms = res.fill_ms, res.kernel_fill_ms, tb.traceback_ms
         out.n_launches, out.rows_per_lane, out.tile_steps = res.n_launches, res.rows_per_lane, res.tile_steps
         out.cells_trace, out.cells_notrace = getattr(res, "cells_trace", 0), getattr(res, "cells_notrace", 0)
-        out.extra = {"stripe": (c0, c1), "stripe_ops": len(tb.ops)}
+        out.border_wait_ms = getattr(res, "border_wait_ms", 0.0)
+        out.extra = {"stripe": (c0, c1), "stripe_ops": len(tb.ops), "overlapped": bool(overlapped)}
         return out
 
     def _gather_ops(self, my_ops):
@@ -281,7 +282,7 @@ class StripedAligner:
             dist.send(E.bytes_tensor(my_ops), dst=0)
         return np.zeros(0, np.uint8)
 
-    def _finish_sw(self, res, m, n, c0, ng, first) -> AlignResult:
+    def _finish_sw(self, res, m, n, c0, ng, first, overlapped=False) -> AlignResult:
         """SW over stripes: the reference's cross-rank arg-max (main.cpp:1151-1177) with its
         first-strict-row-major-maximum rule, then the traceback from the winning cell leftwards
         until the 'X' cell (main.cpp:1233)."""
@@ -325,7 +326,8 @@ class StripedAligner:
         out.fill_ms, out.kernel_fill_ms, out.traceback_ms = res.fill_ms, res.kernel_fill_ms, tb_ms
         out.n_launches, out.rows_per_lane, out.tile_steps = res.n_launches, res.rows_per_lane, res.tile_steps
         out.cells_trace, out.cells_notrace = getattr(res, "cells_trace", 0), getattr(res, "cells_notrace", 0)
-        out.extra = {"stripe": (c0, c0 + ng), "stripe_ops": len(ops), "owner": owner}
+        out.border_wait_ms = getattr(res, "border_wait_ms", 0.0)
+        out.extra = {"stripe": (c0, c0 + ng), "stripe_ops": len(ops), "owner": owner, "overlapped": bool(overlapped)}
         return out
 
     def _on_rank0(self, kind, x, y, mode, go, ge) -> AlignResult:

@@ -26,9 +26,16 @@ def test_gpus_2_starts_two_ranks():
     assert sorted(r[0] for r in reports) == ["0", "1"], p.stdout
     # the ranks got the hardware-queue setting the overlapped stripes need, before any HIP start-up
     assert all(r[1] == "16" for r in reports), reports
-    lines = [json.loads(t) for t in re.findall(r"\{\"launch_check\".*?\}", p.stdout)]
+    lines = [json.loads(t) for t in re.findall(r"\{\"launch_check\".*?\}\]\}", p.stdout)]
     assert len(lines) == 1, p.stdout
     assert lines[0]["n_gpus"] == 2 and lines[0]["rccl_ranks"] == 2 and lines[0]["ranks_reported"] == [0, 1]
+    # the per-rank diagnostics a measured N > 1 line carries (fill / border-wait / traceback ms, K, schedule): one entry per rank
+    sys.path.insert(0, str(ROOT))
+    import bench
+
+    assert [r["rank"] for r in lines[0]["per_rank"]] == [0, 1]
+    assert all(set(r) == set(bench.PER_RANK_KEYS) for r in lines[0]["per_rank"])
+    assert {"fill_ms", "border_wait_ms", "rows_per_lane", "overlapped"} <= set(bench.PER_RANK_KEYS)
 
 
 def test_rank_count_must_match_gpus():

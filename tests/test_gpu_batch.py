@@ -302,3 +302,20 @@ def test_device_resident_pool_gives_identical_results(engine):
     assert np.array_equal(sc2, host["sw"][0])
     with pytest.raises(sa.engine.SeqAlignError):  # a pool needs a size
         engine.set_device_pool(1234, 0)
+
+
+def test_batch_penalty_limit_is_the_documented_one(engine):
+    """include/seqalign_hip.h (sa_sw_batch): penalties beyond (4921) x (|penalty| + 1) <= 1.2e8 are refused with
+    SA_ERR_ARG by the many-pair entry points -- -24 000 passes, -25 000 does not -- while sa_sw takes such a pair."""
+    from sequencealigner_amd.engine import SA_ERR_ARG, SeqAlignError
+
+    pool, ox, lx, oy, ly = protein_pairs(8, seed=3, lo=50, hi=200)
+    ok = engine.sw_batch(pool, ox, lx, oy, ly, "protein", gap_open=-24000.0, gap_extend=-1.0)
+    assert ok[4] == 0
+    with pytest.raises(SeqAlignError) as e:
+        engine.sw_batch(pool, ox, lx, oy, ly, "protein", gap_open=-25000.0, gap_extend=-1.0)
+    assert e.value.code == SA_ERR_ARG and "overflow" in str(e.value)
+    with pytest.raises(SeqAlignError):
+        engine.nw_batch_align(pool, ox, lx, oy, ly, "protein", gap_open=-25000.0, gap_extend=-1.0)
+    one = engine.sw(pool[ox[0]:ox[0] + lx[0]], pool[oy[0]:oy[0] + ly[0]], "protein", -25000.0, -1.0)
+    assert one.score == ok[0][0]  # a penalty that large or larger: both are the best ungapped local alignment

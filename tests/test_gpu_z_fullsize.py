@@ -89,6 +89,44 @@ def test_nw_1mb_checkpointed_bands_equal_banded_oracle(engine, nw_1mb_want, pair
     assert b.cells_notrace == len(x) * len(y) and 0 < b.cells_trace <= 1.01 * len(x) * len(y)
 
 
+def test_sw_1mb_equals_banded_oracle_all_schedules(engine, oracle, pair_1mb):
+    """Smith-Waterman at 1 Mb x 1 Mb (main.cpp:1099-1128, 1182-1265): score, end cell, 'X' cell and the complete op list
+    equal the banded SW oracle's (orc_sw_banded: cells outside |j - i n/m| <= 1024 read as SW's floor 0; it reproduces the
+    reference's own files at 30 000 x 30 004, tests/test_oracle_golden.py), and the launch-per-diagonal schedule and the
+    checkpointed run agree with the one-slab run.  Size-independent properties on top: the moves add up from the stop
+    cell to the end cell, and re-scoring the op list with EDNAFULL -5/-1 (a gap of length L costs -5 - (L - 1)) cannot
+    exceed the reported score (it is the best over all local alignments; the single-pointer traceback, SURVEY Q5, may
+    return a path that scores less)."""
+    x, y = pair_1mb
+    engine.set_option("persistent", 1)
+    a = engine.sw(x, y, "dna")
+    assert a.n_launches == 1
+    want, touched = oracle.sw_banded(x, y, 1024, "dna")
+    assert want.rc == 0 and touched == 0
+    assert (a.score, a.end, a.start) == (want.score, want.end, want.start)
+    assert len(a.ops) == len(want.ops) and np.array_equal(a.ops, want.ops)
+    ops = a.ops
+    assert a.end[0] - int((ops != 1).sum()) == a.start[0] and a.end[1] - int((ops != 2).sum()) == a.start[1]
+    xi = a.end[0] - np.cumsum(ops != 1)
+    yj = a.end[1] - np.cumsum(ops != 2)
+    diag = ops == 0
+    sub = np.where(x[xi[diag]] == y[yj[diag]], 5, -4).sum()  # EDNAFULL on plain ACGT
+    gap = ops != 0
+    opens = gap & np.concatenate([[True], ops[1:] != ops[:-1]])
+    rescored = int(sub) - 5 * int(opens.sum()) - int((gap & ~opens).sum())
+    assert rescored <= a.score and rescored > 0.99 * a.score
+    engine.set_option("persistent", 0)
+    b = engine.sw(x, y, "dna")
+    assert b.n_launches > 1000 and (b.score, b.end, b.start) == (a.score, a.end, a.start) and np.array_equal(a.ops, b.ops)
+    engine.set_option("persistent", 1)
+    engine.set_option("checkpoint_band", 300)
+    try:
+        b = engine.sw(x, y, "dna")
+    finally:
+        engine.set_option("checkpoint_band", 0)
+    assert b.n_launches > 1 and (b.score, b.end, b.start) == (a.score, a.end, a.start) and np.array_equal(a.ops, b.ops)
+
+
 def test_nw_2mb_beyond_device_memory(engine, oracle):
     """2 Mb x 2 Mb: 1 TB of codes cannot be held on one 288 GB device; the engine switches to
     checkpoints + banded recomputation by itself.  Score and complete op list equal the banded

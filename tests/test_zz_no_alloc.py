@@ -37,6 +37,77 @@ def test_noalloc_equals_sw_batch_twice_second_smaller(engine, oracle):
     assert again[4] == 0 and np.array_equal(again[0], second[0])
 
 
+def test_noalloc_allocates_no_device_memory(engine):
+    """The property the entry point exists for: the free device memory is the same before and after its calls.  The
+    ctx's cached workspaces are released first and no allocating entry point runs in between, so a hipMalloc / ensure()
+    that crept back into run_batch_noalloc would show (hipMemGetInfo through the runtime the library is linked against)."""
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    pool, ox, lx, oy, ly = protein_pairs(2000, seed=17, lo=20, hi=900)
+    want = engine.sw_batch(pool, ox, lx, oy, ly, "protein")
+    engine.release_workspace()
+    first = engine.sw_batch_noalloc(pool, ox, lx, oy, ly, "protein")  # anything lazily set up by the runtime happens here
+    before = free_bytes()
+    second = engine.sw_batch_noalloc(pool, ox, lx, oy, ly, "protein")
+    third = engine.sw_batch_noalloc(pool[: ox[500]], ox[:500], lx[:500], oy[:500], ly[:500], "protein")
+    assert free_bytes() == before
+    for k in range(3):
+        assert np.array_equal(want[k], first[k]) and np.array_equal(want[k], second[k]) and np.array_equal(want[k][:500], third[k])
+
+
+def test_noalloc_overlapping_calls_are_refused_not_interleaved(engine):
+    """All calls of the process on one GPU share that GPU's scratch array: a call that arrives while another one holds
+    it gets SA_ERR_ARG ("scratch in use") instead of overwriting its descriptors.  Two ctxs on GPU 0, two threads
+    (ctypes releases the GIL during the call): every call either returns the right results or that refusal."""
+    import threading
+
+    import sequencealigner_amd as sa
+    from sequencealigner_amd.engine import SA_ERR_ARG, SeqAlignError
+
+    pool, ox, lx, oy, ly = protein_pairs(6000, seed=21, lo=300, hi=1000)
+    want = engine.sw_batch(pool, ox, lx, oy, ly, "protein")
+    other = sa.Engine(0)
+    stats = {"ok": 0, "refused": 0, "bad": []}
+    lock = threading.Lock()
+
+    def worker(eng):
+        for _ in range(12):
+            try:
+                got = eng.sw_batch_noalloc(pool, ox, lx, oy, ly, "protein")
+                good = all(np.array_equal(want[k], got[k]) for k in range(3))
+                with lock:
+                    stats["ok"] += 1
+                    if not good:
+                        stats["bad"].append("results differ")
+            except SeqAlignError as e:
+                with lock:
+                    if e.code == SA_ERR_ARG and "scratch in use" in str(e):
+                        stats["refused"] += 1
+                    else:
+                        stats["bad"].append(str(e))
+
+    try:
+        ts = [threading.Thread(target=worker, args=(e,)) for e in (engine, other)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+    finally:
+        other.close()
+    assert not stats["bad"], stats
+    assert stats["ok"] >= 2 and stats["ok"] + stats["refused"] == 24, stats
+    # and the flag is free again afterwards
+    got = engine.sw_batch_noalloc(pool, ox, lx, oy, ly, "protein")
+    assert all(np.array_equal(want[k], got[k]) for k in range(3))
+
+
 def test_noalloc_reads_a_device_pool_in_place(engine):
     import ctypes as C
 
