@@ -143,8 +143,8 @@ int sa_lcs(sa_ctx* ctx, const uint8_t* x, int64_t m, const uint8_t* y, int64_t n
  * A pair with an invalid residue gets score = INT32_MIN and the call returns
  * SA_ERR_INVALID_CODE after finishing the other pairs.
  * Penalties: non-positive, and -- for this and the other many-pair entry points below -- small enough for the batch
- * kernels' 4x-scaled int32 arithmetic over their 1024 x 3895 limits: (4921) x max(|gap_open| + 1, |gap_extend| + 1,
- * max |sub|) <= 1.2e8, i.e. penalties down to about -24 000; beyond that the call returns SA_ERR_ARG (sa_sw / sa_nw
+ * kernels' 4x-scaled int32 arithmetic over their 1024 x 4095 limits: 5121 x max(|gap_open| + 1, |gap_extend| + 1,
+ * max |sub|) <= 1.2e8, i.e. penalties down to -23 431; beyond that the call returns SA_ERR_ARG (sa_sw / sa_nw
  * take such a pair, one at a time). */
 int sa_sw_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x,
                 const int64_t* off_y, const int32_t* len_y, int64_t n_pairs,
@@ -158,8 +158,9 @@ int sa_sw_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const in
  * and reads the results back before it returns.  Its device
  * scratch (sequence staging, pair descriptors, per-pair results, error flag, scoring tables) is one file-scope
  * `static __device__` array of SA_NOALLOC_MAX_SEQ_BYTES + 48 + 12 bytes per pair of SA_NOALLOC_MAX_PAIRS + 2 KiB
- * (33 MiB) that every GPU the library runs on holds until the process ends; sa_create() looks its address up once per device and pins the
- * 1 MB host staging block the call uses.  Limits, rejected with SA_ERR_ARG / SA_ERR_UNSUPPORTED and a message:
+ * (33 MiB) that every GPU this entry point has run on holds until the process ends (the array is a code object of its
+ * own, loaded by the entry point's first call on a device, which also looks its address up, once per device);
+ * sa_create() pins the 1 MB host staging block the call uses.  Limits, rejected with SA_ERR_ARG / SA_ERR_UNSUPPORTED and a message:
  * n_pairs <= SA_NOALLOC_MAX_PAIRS; unless a device pool is set (sa_batch_set_device_pool: the sequences are then read
  * in place), every pair must end within the first SA_NOALLOC_MAX_SEQ_BYTES of `seqs`; every pair must fit the batch
  * kernels (len_x <= 1024, len_y <= 3895: sa_sw_batch's single-pair fallback allocates and is not taken).

@@ -285,6 +285,12 @@ int launcher_rank() {
 
 int main(int argc, char** argv) {
   sa_ctx* ctx = nullptr;
+  // SA_TIMING=1: where a cold process spends its time (stderr), cf. bench.py small_pairs
+  const bool timing = std::getenv("SA_TIMING") != nullptr;
+  const auto tp0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (timing) std::fprintf(stderr, "[cli_timing] %-24s %8.3f ms since main\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
+  };
   try {
     Options o;
     for (int i = 1; i < argc; ++i) {  // main.cpp:1731-1776
@@ -345,9 +351,11 @@ int main(int argc, char** argv) {
       return 0;
     }
     const Seq q = read_fasta(o.query), t = read_fasta(o.target);
+    lap("args + FASTA read");
     if (o.choice >= 1 && o.choice <= 4) {
       ctx = sa_create(o.device);
       if (!ctx) throw std::runtime_error("no gfx950 GPU available (this build has no CPU path)");
+      lap("sa_create");
       if (o.choice == 4) {
         run_one(ctx, 1, o, q, t);
         run_one(ctx, 2, o, q, t);
@@ -355,6 +363,7 @@ int main(int argc, char** argv) {
       } else {
         run_one(ctx, o.choice, o, q, t);
       }
+      lap("align + result files");
     } else {
       std::cerr << "Invalid method. Use --choice 1/2/3/4.\n";
     }
@@ -362,5 +371,6 @@ int main(int argc, char** argv) {
     std::cerr << "Error: " << e.what() << "\n";  // and exit 0, like the reference
   }
   if (ctx) sa_destroy(ctx);
+  lap("sa_destroy");
   return 0;
 }

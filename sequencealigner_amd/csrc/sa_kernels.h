@@ -73,6 +73,8 @@ struct FillArgs {
   // persistent pipeline over column stripes: borders cross GPUs while the kernel runs
 #ifdef SA_DEBUG_HANDOFF
   long long* dbg;        // [S][4]: start clock, end clock, re-read episodes, re-reads
+  long long* dbgblk;     // [8][dbgblk_stride]: clock at the start of every 64-step block of eight chosen strips (tools/analyze_blocks.py)
+  int dbgblk_stride;
 #endif
   const int* rows_in;    // rows of `lb` that have arrived (raised by stripe_signal on the receive stream); null: all there
   int* chunk_done;       // [chunks] strips of border chunk k whose `rb` rows are written (stripe_wait polls it); null: no right neighbour
@@ -731,8 +733,19 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
 #ifdef SA_DEBUG_HANDOFF
     const long long dbg_t0 = wall_clock64();
 #endif
+#ifdef SA_DEBUG_HANDOFF
+    int dbg_slot = -1;
+    {
+      const int picks[8] = {0, 1, 2, 3, a.S / 2, a.S / 2 + 1, a.S - 2, a.S - 1};
+      for (int q = 0; q < 8; ++q)
+        if (picks[q] == s) dbg_slot = q;
+    }
+#endif
 #pragma unroll 1
     for (int b = 0; b < NB && !dead; ++b) {
+#ifdef SA_DEBUG_HANDOFF
+      if (a.dbgblk && dbg_slot >= 0 && lane == 0 && b < a.dbgblk_stride) a.dbgblk[(size_t)dbg_slot * a.dbgblk_stride + b] = wall_clock64();
+#endif
       const int Tb = 64 * b;
       const int yb = YSCALE ? ny * G::ROWB : ny;
       const bool interior = (Tb >= 64) && (Tb + 63 < a.n);

@@ -22,30 +22,11 @@
 #include "sa_batch.h"
 #include "sa_kernels.h"
 #include "sa_launch.h"
+#include "sa_noalloc.h"
 #include "sa_lcsbits.h"
 #include "sa_tables.h"
 
 using namespace sa;
-
-// ---- sa_sw_batch_noalloc: the one entry point that allocates nothing ----------------------------
-// Its device scratch (sequence staging, pair descriptors, per-pair results, error flag, scoring tables) is
-// this file-scope array instead of the ctx's hipMalloc'ed workspaces.  Every GPU the library is loaded on
-// holds its own copy at its own address until the process ends.  In host code the NAME of the array is
-// only a handle: the device address comes from hipGetSymbolAddress, once per device (na_scratch_for_device,
-// called by sa_create with that device current), and only that pointer is ever handed to kernels, memsets
-// and copies.
-namespace {
-constexpr size_t kNaMaxPairs = SA_NOALLOC_MAX_PAIRS;
-constexpr size_t kNaMaxSeq = SA_NOALLOC_MAX_SEQ_BYTES;
-constexpr size_t kNaDescOff = kNaMaxSeq + 256;                               // sequences first (+ slack for the kernels' reads)
-constexpr size_t kNaOutOff = kNaDescOff + kNaMaxPairs * sizeof(PairDesc);  // score | end_i | end_j, kNaMaxPairs ints each
-constexpr size_t kNaErrOff = kNaOutOff + 3 * kNaMaxPairs * 4;                // 64 bytes
-constexpr size_t kNaSubOff = kNaErrOff + 64;                                 // 1024 bytes
-constexpr size_t kNaMapOff = kNaSubOff + 1024;                               // 256 bytes
-constexpr size_t kNaBytes = (kNaMapOff + 256 + 255) & ~size_t(255);
-constexpr size_t kNaHostBytes = kNaMaxPairs * sizeof(PairDesc) + 3 * kNaMaxPairs * 4 + 64;  // pinned staging per ctx
-}  // namespace
-static __device__ __align__(256) unsigned char scratch[kNaBytes];
 
 namespace {
 
@@ -97,7 +78,8 @@ struct sa_ctx {
   } last;
   size_t trace_budget = 0;  // bytes of codes one call may hold; 0 = 88 % of the device memory
   int force_band = 0;       // > 0: always checkpoint and recompute this many strips at a time
-  // sa_sw_batch_noalloc: this device's address of `scratch` and a page-locked staging block, both set up by sa_create
+  // sa_sw_batch_noalloc: this device's address of `scratch` (sa_noalloc.hip; looked up on the first call) and a page-locked
+  // staging block set up by sa_create
   unsigned char* na_scratch = nullptr;
   unsigned char* na_host = nullptr;
 };
@@ -277,8 +259,9 @@ int choose_stripe_K(const sa_ctx* ctx, int kind, int64_t m, int64_t n, int64_t n
     const double step = (cell * K + step0) * 4.0;
     const double S = std::ceil((double)m / (64.0 * K));
     const double hops = n > 0 ? std::max(0.0, std::round((double)n_total / (double)n) - 1.0) : 0.0;
-    const double first = ((double)n + (R > 0 ? (double)R / (64.0 * K) : 1.0) * strip_lag(step)) * step;
-    const double est = hops * first + pipeline_steps(S, waves, (double)n + 63.0, strip_lag(step)) * step;
+    const double lag = strip_lag(step);
+    const double first = ((double)n + (R > 0 ? (double)R / (64.0 * K) : 1.0) * lag) * step;
+    const double est = hops * first + pipeline_steps(S, waves, (double)n + 63.0, lag) * step;
     if (est < best) {
       best = est;
       bestK = K;
@@ -648,7 +631,6 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   a.rowbest = (int*)ctx->rowbest.p;
   a.rowbestc = a.rowbest ? a.rowbest + m : nullptr;
   a.score_out = d_score;
-
   const size_t lds = (kind == KIND_LCS && !lprof) ? 0 : (size_t)alpha * 64 * PW * 4 * kWavesPerBlock;
   auto f_lo = [&](int s) { return (long long)s + (64LL * s) / C; };
   auto f_hi = [&](int s) { return (long long)s + (64LL * s + n + 62) / C; };
@@ -669,6 +651,19 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
       }
       HIPCK(ctx, hipMemsetAsync(dbgbuf, 0, (size_t)S * 32, st));
       a.dbg = (long long*)dbgbuf;
+      static void* blkbuf = nullptr;
+      static size_t blkcap = 0;
+      const int NBd = (n + 126) / 64;
+      if (getenv("SA_DEBUG_BLOCKS_FILE")) {
+        if (blkcap < (size_t)NBd * 64) {
+          if (blkbuf) (void)hipFree(blkbuf);
+          HIPCK(ctx, hipMalloc(&blkbuf, (size_t)NBd * 64));
+          blkcap = (size_t)NBd * 64;
+        }
+        HIPCK(ctx, hipMemsetAsync(blkbuf, 0, (size_t)NBd * 64, st));
+        a.dbgblk = (long long*)blkbuf;
+        a.dbgblk_stride = NBd;
+      }
     }
 #endif
     a.err = (int*)ctx->small.p + 40;  // byte 160 of the small block, read back with the score
@@ -738,6 +733,16 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   if (persist && a.dbg) {
     std::vector<long long> h((size_t)4 * S);
     HIPCK(ctx, hipStreamSynchronize(st));
+    if (a.dbgblk) {  // per-block clocks of eight strips: raw int64 [8][stride], little endian, behind a 2-int header
+      std::vector<long long> hb((size_t)8 * a.dbgblk_stride);
+      HIPCK(ctx, hipMemcpy(hb.data(), a.dbgblk, hb.size() * 8, hipMemcpyDeviceToHost));
+      if (FILE* f = fopen(getenv("SA_DEBUG_BLOCKS_FILE"), "wb")) {
+        const int hdr[2] = {a.dbgblk_stride, S};
+        fwrite(hdr, 4, 2, f);
+        fwrite(hb.data(), 8, hb.size(), f);
+        fclose(f);
+      }
+    }
     HIPCK(ctx, hipMemcpy(h.data(), a.dbg, h.size() * 8, hipMemcpyDeviceToHost));
     double lag = 0, dur = 0, ep = 0, rr = 0;
     const int lim = std::min(S, grid_blocks * kWavesPerBlock);
@@ -1627,39 +1632,6 @@ int run_batch(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int3
   return SA_OK;
 }
 
-// Device address of `scratch` on the CURRENT device, looked up once per device.
-std::mutex g_na_mu;
-unsigned char* g_na_ptr[64] = {nullptr};
-// Every ctx and thread of the process shares a device's one array: a call holds this flag from its first write to the
-// array until its results are on the host, and a second call arriving meanwhile is refused, not interleaved.
-std::atomic<int> g_na_busy[64];
-struct NaBusy {
-  int dev;
-  bool held;
-  explicit NaBusy(int d) : dev(d), held(g_na_busy[d].exchange(1, std::memory_order_acquire) == 0) {}
-  ~NaBusy() {
-    if (held) g_na_busy[dev].store(0, std::memory_order_release);
-  }
-  NaBusy(const NaBusy&) = delete;
-  NaBusy& operator=(const NaBusy&) = delete;
-};
-hipError_t na_scratch_for_device(int dev, unsigned char** out) {
-  *out = nullptr;
-  if (dev < 0 || dev >= 64) return hipErrorInvalidDevice;
-  std::lock_guard<std::mutex> lk(g_na_mu);
-  if (!g_na_ptr[dev]) {
-    void* p = nullptr;
-    const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      return e;
-    }
-    g_na_ptr[dev] = (unsigned char*)p;
-  }
-  *out = g_na_ptr[dev];
-  return hipSuccess;
-}
-
 // sa_sw_batch with every device buffer inside `scratch` and every host buffer inside the ctx's pinned staging
 // block: no hipMalloc / hipFree / hipHostMalloc, no std::vector.  Same kernels, same results.
 int run_batch_noalloc(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, const int32_t* len_x, const int64_t* off_y,
@@ -1667,7 +1639,7 @@ int run_batch_noalloc(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, co
                       float* kernel_ms) {
   if (!ctx) return SA_ERR_ARG;
   if (kernel_ms) *kernel_ms = 0.f;
-  if (!ctx->na_scratch || !ctx->na_host) return fail(ctx, SA_ERR_HIP, "sa_sw_batch_noalloc: the scratch array was not set up by sa_create");
+  if (!ctx->na_host) return fail(ctx, SA_ERR_HIP, "sa_sw_batch_noalloc: the pinned staging block was not set up by sa_create");
   const bool resident = ctx->dev_pool != nullptr;
   if (n_pairs < 0 || (n_pairs > 0 && ((!seqs && !resident) || !off_x || !len_x || !off_y || !len_y || !score || !end_i || !end_j)))
     return fail(ctx, SA_ERR_ARG, "bad batch arguments");
@@ -1682,6 +1654,12 @@ int run_batch_noalloc(sa_ctx* ctx, const uint8_t* seqs, const int64_t* off_x, co
   HIPCK(ctx, hipSetDevice(ctx->device));
   hipStream_t st = ctx->stream;
   const int alpha = sc->alpha;
+  // this device's address of the scratch array: looked up on the entry point's first call on the device (with the device
+  // current), kept per device in sa_noalloc.hip and per ctx here
+  if (!ctx->na_scratch) {
+    const hipError_t e = na_scratch_for_device(ctx->device, &ctx->na_scratch);
+    if (e != hipSuccess || !ctx->na_scratch) return fail(ctx, SA_ERR_HIP, "sa_sw_batch_noalloc: hipGetSymbolAddress(scratch) failed: %s", hipGetErrorString(e));
+  }
   const NaBusy busy(ctx->device);  // released on every return path below
   if (!busy.held) return fail(ctx, SA_ERR_ARG, "sa_sw_batch_noalloc: scratch in use (another call on GPU %d has not returned yet)", ctx->device);
 
@@ -1790,11 +1768,18 @@ struct Builtin {
 extern "C" {
 
 sa_ctx* sa_create(int device_id) {
+  static const bool timing = getenv("SA_TIMING") != nullptr;
+  const auto tp0 = std::chrono::steady_clock::now();
+  auto lap = [&](const char* what) {
+    if (timing) fprintf(stderr, "[sa_create] %-28s %8.3f ms since call\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count());
+  };
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return nullptr;
+  lap("hipGetDeviceCount (HIP init)");
   if (hipSetDevice(device_id) != hipSuccess) return nullptr;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device_id) != hipSuccess) return nullptr;
+  lap("set device, properties");
   if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
     fprintf(stderr, "seqalign_hip: device %d is %s; this library carries gfx950 code only\n", device_id, prop.gcnArchName);
     return nullptr;
@@ -1814,14 +1799,16 @@ sa_ctx* sa_create(int device_id) {
       return nullptr;
     }
   c->err.reserve(512);
-  // sa_sw_batch_noalloc: this device's address of the scratch array (the device is current here) and the pinned
-  // staging block, so that the entry point itself never allocates.  A failure here only disables that entry point.
-  if (na_scratch_for_device(device_id, &c->na_scratch) != hipSuccess) c->na_scratch = nullptr;
+  lap("stream, events");
+  // sa_sw_batch_noalloc: the pinned staging block, so that the entry point itself never allocates (its device scratch is
+  // a static array in a code object of its own, sa_noalloc.hip, whose address the entry point looks up on its first call
+  // on this device: a process that never calls it never loads those 33 MiB).  A failure here only disables that entry point.
   void* hp = nullptr;
   if (hipHostMalloc(&hp, kNaHostBytes, hipHostMallocDefault) == hipSuccess)
     c->na_host = (unsigned char*)hp;
   else
     (void)hipGetLastError();
+  lap("pinned staging block");
   return c;
 }
 

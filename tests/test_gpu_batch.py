@@ -305,15 +305,16 @@ def test_device_resident_pool_gives_identical_results(engine):
 
 
 def test_batch_penalty_limit_is_the_documented_one(engine):
-    """include/seqalign_hip.h (sa_sw_batch): penalties beyond (4921) x (|penalty| + 1) <= 1.2e8 are refused with
-    SA_ERR_ARG by the many-pair entry points -- -24 000 passes, -25 000 does not -- while sa_sw takes such a pair."""
+    """include/seqalign_hip.h (sa_sw_batch): penalties beyond 5121 x (|penalty| + 1) <= 1.2e8 are refused with
+    SA_ERR_ARG by the many-pair entry points -- -23 431 passes, -23 432 does not -- while sa_sw takes such a pair."""
     from sequencealigner_amd.engine import SA_ERR_ARG, SeqAlignError
+    from sequencealigner_amd.synth import protein_pairs
 
     pool, ox, lx, oy, ly = protein_pairs(8, seed=3, lo=50, hi=200)
-    ok = engine.sw_batch(pool, ox, lx, oy, ly, "protein", gap_open=-24000.0, gap_extend=-1.0)
+    ok = engine.sw_batch(pool, ox, lx, oy, ly, "protein", gap_open=-23431.0, gap_extend=-1.0)
     assert ok[4] == 0
     with pytest.raises(SeqAlignError) as e:
-        engine.sw_batch(pool, ox, lx, oy, ly, "protein", gap_open=-25000.0, gap_extend=-1.0)
+        engine.sw_batch(pool, ox, lx, oy, ly, "protein", gap_open=-23432.0, gap_extend=-1.0)
     assert e.value.code == SA_ERR_ARG and "overflow" in str(e.value)
     with pytest.raises(SeqAlignError):
         engine.nw_batch_align(pool, ox, lx, oy, ly, "protein", gap_open=-25000.0, gap_extend=-1.0)
