@@ -116,4 +116,11 @@ void launch_persistent_kind(int kind, int K, dim3 grid, size_t lds, hipStream_t 
     launch_persistent_lcs(K, grid, lds, st, a, notrace, lprof, frac);
 }
 
+void launch_group_kind(int kind, int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a, bool notrace, bool frac) {
+  if (kind == KIND_NW)
+    launch_group_nw(K, grid, lds, st, a, notrace, frac);
+  else
+    launch_group_sw(K, grid, lds, st, a, notrace, frac);
+}
+
 }  // namespace sa

@@ -16,7 +16,11 @@ void launch_fill_kind(int kind, int K, int fl, dim3 grid, size_t lds, hipStream_
 // lprof: profile-driven LCS (small alphabets; also K = 16); frac: NW with a fractional gap penalty
 void launch_persistent_kind(int kind, int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a, bool notrace, bool lprof,
                             bool frac);
-// per-kind pieces of the two functions above (one translation unit each)
+// fill_group<kind, K, flags> (sa_group.h; NW and SW): four consecutive strips per workgroup, hand-offs through LDS
+void launch_group_kind(int kind, int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a, bool notrace, bool frac);
+void launch_group_nw(int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a, bool notrace, bool frac);
+void launch_group_sw(int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a, bool notrace, bool frac);
+// per-kind pieces of the functions above (one translation unit each)
 void launch_fill_nw(int K, int fl, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a);
 void launch_fill_sw(int K, int fl, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a);
 void launch_fill_lcs(int K, int fl, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a);

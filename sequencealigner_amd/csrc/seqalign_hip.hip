@@ -21,6 +21,7 @@
 #include "../../include/seqalign_hip.h"
 #include "sa_batch.h"
 #include "sa_kernels.h"
+#include "sa_group.h"
 #include "sa_launch.h"
 #include "sa_noalloc.h"
 #include "sa_lcsbits.h"
@@ -55,6 +56,7 @@ struct sa_ctx {
   int bits_wpb = 0; // bit-vector LCS: waves per workgroup, 0 = automatic (option "lcs_bits_waves_per_block", for measurements)
   int lcs_bits = 1; // 1: LCS of a whole pair over at most 63 distinct bytes runs as bit-vector arithmetic (sa_lcsbits.hip)
   int wps = 1;      // persistent kernel: waves per SIMD to launch
+  int group = 0;    // 1: NW / SW fills of a whole matrix run fill_group (sa_group.h: four strips per workgroup, LDS hand-offs)
   int max_wg = 0;   // persistent kernels: at most this many workgroups per launch (0: as many as the GPU holds); tests use it to
                     // make small inputs take several rounds of tickets (ring-slot reuse, generations)
   int n_cu = 256;
@@ -453,6 +455,8 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   // what the call holds besides the codes: the hand-off ring of a one-slab run (8 GB at 1 Mb x 1 Mb), the query profile
   // and the O(m + n) buffers.  They come out of the same memory, so they count against the same budget.
   const int grid_blocks = std::min((S + kWavesPerBlock - 1) / kWavesPerBlock, persist_wg_cap(ctx));
+  // fill_group (sa_group.h): NW / SW over a whole matrix (no border traffic while it runs), profile + rings within 64 KB of LDS
+  const bool group = persist && ctx->group && kind != KIND_LCS && !striped && group_lds_bytes(alpha, PW) <= ((size_t)64 << 10);
   const size_t ring_slab = persist ? (size_t)std::min(S + 1, grid_blocks * kWavesPerBlock + 2) : 2;
   const size_t fixed_bytes = 2 * ring_slab * NP * 4 + (size_t)S * alpha * 64 * PW * 4 + (size_t)S * NF * 64 * 4 + ((size_t)m + 1) * 8 +
                              (kind == KIND_SW ? (size_t)2 * m * 4 : 0) + 2 * ((size_t)m + n) + rows_pad + (size_t)Tend + ((size_t)4 << 20);
@@ -686,7 +690,10 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
   if (persist) {
     const dim3 grid(grid_blocks);
-    launch_persistent_kind(kind, K, grid, lds, st, a, ckpt || no_tb, lprof, kind == KIND_NW && (fl & FLAG_FRAC) != 0);
+    if (group)
+      launch_group_kind(kind, K, grid, group_lds_bytes(alpha, PW), st, a, ckpt || no_tb, kind == KIND_NW && (fl & FLAG_FRAC) != 0);
+    else
+      launch_persistent_kind(kind, K, grid, lds, st, a, ckpt || no_tb, lprof, kind == KIND_NW && (fl & FLAG_FRAC) != 0);
     launches = 1;
     // border hand-offs, all enqueued now and resolved on the device while the fill runs
     for (int64_t k = 0; k < n_chunks && (a.rows_in || a.chunk_done); ++k) {
@@ -1788,6 +1795,8 @@ sa_ctx* sa_create(int device_id) {
   c->device = device_id;
   c->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   if (const char* e = getenv("SA_PERSIST")) c->persist = atoi(e);
+  if (const char* e = getenv("SA_GROUP")) c->group = atoi(e);
+  if (const char* e = getenv("SA_WPS")) c->wps = std::max(1, std::min(4, atoi(e)));
   if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) {
     delete c;
     return nullptr;
@@ -1863,6 +1872,8 @@ int sa_set_option(sa_ctx* c, const char* name, int64_t value) {
   } else if (!strcmp(name, "max_workgroups")) {  // 0: as many as the GPU holds
     if (value < 0) return fail(c, SA_ERR_ARG, "max_workgroups must be >= 0");
     c->max_wg = (int)std::min<int64_t>(value, 1 << 20);
+  } else if (!strcmp(name, "group")) {  // 1: fill_group where it applies (NW / SW, whole matrix); 0: fill_persistent
+    c->group = value != 0;
   } else if (!strcmp(name, "waves_per_simd")) {
     if (value < 1 || value > 4) return fail(c, SA_ERR_ARG, "waves_per_simd must be 1..4");
     c->wps = (int)value;
