@@ -457,7 +457,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   const int grid_blocks = std::min((S + kWavesPerBlock - 1) / kWavesPerBlock, persist_wg_cap(ctx));
   // fill_group (sa_group.h): NW / SW over a whole matrix (no border traffic while it runs), profile + rings within 64 KB of LDS
   const bool group = persist && ctx->group && kind != KIND_LCS && !striped && group_lds_bytes(alpha, PW) <= ((size_t)64 << 10);
-  const size_t ring_slab = persist ? (size_t)std::min(S + 1, grid_blocks * kWavesPerBlock + 2) : 2;
+  const size_t ring_slab = persist ? (size_t)std::min(S + 1, grid_blocks * kWavesPerBlock + 2) + (group ? 1 : 0) : 2;
   const size_t fixed_bytes = 2 * ring_slab * NP * 4 + (size_t)S * alpha * 64 * PW * 4 + (size_t)S * NF * 64 * 4 + ((size_t)m + 1) * 8 +
                              (kind == KIND_SW ? (size_t)2 * m * 4 : 0) + 2 * ((size_t)m + n) + rows_pad + (size_t)Tend + ((size_t)4 << 20);
   const bool ckpt = !no_tb && !sd && ((size_t)S * strip_trace_bytes + fixed_bytes > budget || (ctx->force_band > 0 && persist));
@@ -478,7 +478,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   // of a 1 Mb x 1 Mb pair is 250 GB, the checkpoint rows of a 2 Mb x 2 Mb pair 62 GB): if any of them
   // has to grow, let all of them go first so that the new sizes are what has to fit.
   {
-    const size_t need_bot = (size_t)2 * ring * NP * 4, need_trace = no_tb ? 0 : (size_t)band * strip_trace_bytes;
+    const size_t need_bot = (size_t)2 * (ring + (group ? 1 : 0)) * NP * 4, need_trace = no_tb ? 0 : (size_t)band * strip_trace_bytes;
     const size_t need_dp = dump ? ((size_t)m + 1) * ((size_t)n + 1) * 4 : 0;
     if (need_bot > ctx->bot.cap || need_trace > ctx->trace.cap || need_dp > ctx->dpbuf.cap) {
       release(ctx->bot);
@@ -486,7 +486,7 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
       release(ctx->dpbuf);
     }
   }
-  if ((rc = ensure(ctx, ctx->bot, (size_t)2 * ring * NP * 4))) return rc;
+  if ((rc = ensure(ctx, ctx->bot, (size_t)2 * (ring + (group ? 1 : 0)) * NP * 4))) return rc;  // fill_group: + one slot nobody writes
   if ((rc = ensure(ctx, ctx->state, (size_t)S * NF * 64 * 4))) return rc;
   if ((rc = ensure(ctx, ctx->small, 256))) return rc;
   const size_t pbuf_ints = (size_t)S + 64 + (size_t)n_chunks;  // [0] ticket, [32] rows_in, [34..35] wait ticks, [64 + S ..] chunk_done
@@ -754,6 +754,12 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
     double lag = 0, dur = 0, ep = 0, rr = 0;
     const int lim = std::min(S, grid_blocks * kWavesPerBlock);
     for (int q = 1; q < lim; ++q) lag += (double)(h[4 * q] - h[4 * (q - 1)]);
+    {  // fill_group: hops inside a workgroup and hops between workgroups apart
+      double in = 0, out = 0;
+      int nin = 0, nout = 0;
+      for (int q = 1; q < lim; ++q) (q % kWavesPerBlock ? (++nin, in) : (++nout, out)) += (double)(h[4 * q + 1] - h[4 * (q - 1) + 1]);
+      fprintf(stderr, "[handoff] group=%d: end-to-end lag of strips 4g+1..3 %.2f us, of strips 4g %.2f us\n", (int)group, in / std::max(1, nin) / 100.0, out / std::max(1, nout) / 100.0);
+    }
     for (int q = 0; q < S; ++q) dur += (double)(h[4 * q + 1] - h[4 * q]), ep += (double)h[4 * q + 2], rr += (double)h[4 * q + 3];
     fprintf(stderr, "[handoff] K=%d S=%d n=%d: mean start-to-start lag of the first %d strips %.2f us, mean strip duration %.1f us (%.1f ns/step), "
             "re-read episodes per strip %.1f, re-reads per strip %.1f; span first start -> last end %.1f us; strip 0 alone: %.1f ns/step\n", K, S, n, lim, lag / std::max(1, lim - 1) / 100.0,

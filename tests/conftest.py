@@ -38,12 +38,14 @@ def engine(_engine_session):
     eng.set_option("waves_per_simd", 1)
     eng.set_option("lcs_bits", 1)
     eng.set_option("max_workgroups", 0)
+    eng.set_option("group", 0)
     eng.set_tuning(0, 0)
     yield eng
     eng.set_option("persistent", 1)
     eng.set_option("waves_per_simd", 1)
     eng.set_option("lcs_bits", 1)
     eng.set_option("max_workgroups", 0)
+    eng.set_option("group", 0)
     eng.set_tuning(0, 0)
 
 
