@@ -80,6 +80,10 @@ struct FillArgs {
   int* chunk_done;       // [chunks] strips of border chunk k whose `rb` rows are written (stripe_wait polls it); null: no right neighbour
   int strips_per_chunk;
   unsigned long long* wait_ticks;  // column stripes: 100 MHz ticks the strips of this launch spent waiting for rows of `lb` (summed over strips)
+  // bit-vector LCS over column stripes (sa_lcsbits.hip): the stripe's left / right border column as vertical-difference
+  // bits, one dword per (strip, lane) = 32 rows; null: the matrix' own column 0 (all set) / no right neighbour
+  const uint32_t* vleft;
+  uint32_t* vright;
 };
 
 // Agent-scope relaxed atomic accesses (global_load / global_store .. sc1: the store writes through to L2, the
@@ -561,10 +565,16 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_tile(const FillArgs 
 // (measured: one strip alone, tools/perf_step.py); a 16-step sub-block of NW / SW lasts 0.73 us (K = 1) .. 2.6 us
 // (K = 8) and one sub-block ahead is enough (two cost K = 8 its registers: 164 -> 179 ns per step); the LCS cell is
 // cheaper (0.56 us per sub-block at K = 1) and asks two sub-blocks ahead.  Must divide 4 (sub-blocks per block).
+constexpr int kSubBlocksPerBlock = 4;  // a 64-step block is four 16-step sub-blocks (run_block_p expands them in line)
 template <int KIND, int K>
 struct HandoffDepth {
   static constexpr int D = KIND == KIND_LCS ? 2 : 1;
+  // pend[(sub + 1) % D] is the request issued D sub-blocks earlier only if the block's sub-block count is a multiple of D
+  static_assert(kSubBlocksPerBlock % D == 0, "the request distance must divide the sub-blocks of a block");
 };
+// The generation scheme of the hand-off records (ho_store) holds while the ring has at least two slots more than the
+// launch has waves, or one slot per strip (+ the slot of matrix row 0): checked on the host before every launch.
+inline bool handoff_ring_ok(int ring, int strips, int grid_waves) { return ring >= strips + 1 || ring >= grid_waves + 2; }
 
 // Take the hand-off records of the sub-block that starts at step Ts (lanes 0..15: columns Ts .. Ts+15), requested
 // D sub-blocks earlier into `cur`, install them in the in-buffers and request those D sub-blocks further on into

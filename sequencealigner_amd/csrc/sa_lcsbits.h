@@ -20,6 +20,9 @@ int bits_slot_len(int n);
 // the fill: FillArgs as for fill_persistent (W = steps per strip, trace = [S][W][64] dwords or null: score only)
 // waves_per_block: 1, 2 or 4 waves per workgroup (each wave works on its own; fewer per workgroup spreads them over more CUs)
 void bits_launch_fill(hipStream_t st, int grid_blocks, int waves_per_block, const FillArgs& a);
+// column stripes: (H, E) border rows r_lo + 1 .. r_hi <-> vertical-difference bits r_lo .. r_hi - 1 (r_lo a multiple of 32)
+void bits_launch_border_to_bits(hipStream_t st, const int2* lb, int m, int r_lo, int r_hi, uint32_t* vbits);
+void bits_launch_bits_to_border(hipStream_t st, const uint32_t* vbits, int m, int r_lo, int r_hi, int2* rb);
 // the walker over that format (TraceArgs::xs / ys / W set)
 void bits_launch_traceback(hipStream_t st, const TraceArgs& t);
 

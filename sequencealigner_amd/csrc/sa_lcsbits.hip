@@ -84,6 +84,25 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
     };
 
     uint32_t V = 0xffffffffu;  // column 0 of L is all zeros: no vertical step anywhere
+    if (a.vleft) {  // column stripe: the vertical differences of the column left of this stripe
+      if (a.rows_in) {  // they cross from the neighbour GPU while this kernel runs: the strip's rows must have arrived
+        const int need = min(a.m, (s + 1) * kBitsStripRows);
+        if (ld_coherent(a.rows_in) < need) {
+          const long long t0 = wall_clock64();
+          int spins = 0;
+          while (ld_coherent(a.rows_in) < need) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > a.spin_limit || ((spins & 255) == 0 && ld_coherent(a.err) != 0)) {
+              dead = true;
+              break;
+            }
+          }
+          if (lane == 0 && a.wait_ticks) atomicAdd(a.wait_ticks, (unsigned long long)(wall_clock64() - t0));
+        }
+        asm volatile("" ::: "memory");  // the border load stays behind the poll
+      }
+      V = (uint32_t)ld_coherent(reinterpret_cast<const int*>(a.vleft) + s * 64 + lane);
+    }
     // What travels down the lanes is not the symbol but the LDS address of its mask for the receiving lane: lane l
     // takes the address lane l-1 used kBitsSkew steps ago, plus 4 (prof[sym][lane] is a dword per lane) -- one
     // v_add_u32_dpp; lane 0 takes the next entry of the in-buffer yb (the block's 64 symbols, rotated once per step).
@@ -210,6 +229,15 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
       if (lane == 0) st_coherent(a.err, 1);
       break;
     }
+    if (a.vright) {  // the stripe's last column for the right neighbour (bits_to_border turns it into border rows)
+      if (a.chunk_done) {
+        st_coherent(reinterpret_cast<int*>(a.vright) + s * 64 + lane, (int)V);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(a.chunk_done + s / a.strips_per_chunk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        a.vright[s * 64 + lane] = V;
+      }
+    }
     // L[m][n] = the vertical steps of the last column = the clear bits among the rows < m
     const int r0 = (s * 64 + lane) * kBitsRowsPerLane;
     const int nvalid = min(max(a.m - r0, 0), 32);
@@ -235,6 +263,77 @@ __global__ void build_bits_profile(const uint8_t* __restrict__ xs, int m, int al
     }
     prof[g] = w;
   }
+}
+
+// Column stripes travel as (H, E) border rows (include/seqalign_hip.h: 8 bytes per matrix row, H = L[i][c]); the kernel
+// above wants vertical-difference bits.  Rows r_lo + 1 .. r_hi of a border -> bits r_lo .. r_hi - 1 (bit r set iff
+// L[r + 1] = L[r]; rows beyond m: set).  r_lo is a multiple of 32.
+__global__ void border_to_bits(const int2* __restrict__ lb, int m, int r_lo, int r_hi, uint32_t* __restrict__ vbits) {
+  const int nd = (r_hi - r_lo + 31) / 32;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < nd; t += gridDim.x * blockDim.x) {
+    const int r0 = r_lo + 32 * t;
+    uint32_t w = 0;
+    int prev = r0 < m ? lb[r0].x : 0;
+#pragma unroll 8
+    for (int b = 0; b < 32; ++b) {
+      const int r = r0 + b;
+      bool same = true;
+      if (r < m) {
+        const int cur = lb[r + 1].x;
+        same = cur == prev;
+        prev = cur;
+      }
+      if (same) w |= 1u << b;
+    }
+    vbits[r0 / 32] = w;
+  }
+}
+
+// ... and back: bits r_lo .. r_hi - 1 of the stripe's last column -> border rows r_lo + 1 .. r_hi,
+// L[i] = L[r_lo] + the clear bits among the rows r_lo .. i - 1 (one workgroup; the fill kernel may still be running: sc1 loads)
+__global__ void __launch_bounds__(256) bits_to_border(const uint32_t* __restrict__ vbits, int m, int r_lo, int r_hi, int2* __restrict__ rb) {
+  __shared__ int part[256];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = r_lo == 0 ? 0 : rb[r_lo].x;
+  __syncthreads();
+  const int nd = (r_hi - r_lo + 31) / 32;
+  for (int t0 = 0; t0 < nd; t0 += 256) {
+    const int t = t0 + threadIdx.x;
+    const int r0 = r_lo + 32 * t;
+    uint32_t w = 0xffffffffu;
+    if (t < nd) w = (uint32_t)ld_coherent(reinterpret_cast<const int*>(vbits) + r0 / 32);
+    const int nvalid = min(max(m - r0, 0), 32);
+    const uint32_t vm = nvalid == 32 ? 0xffffffffu : ((1u << nvalid) - 1u);
+    const int cnt = __builtin_popcount(~w & vm);
+    part[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {  // inclusive scan
+      const int v = threadIdx.x >= o ? part[threadIdx.x - o] : 0;
+      __syncthreads();
+      part[threadIdx.x] += v;
+      __syncthreads();
+    }
+    int L = carry + part[threadIdx.x] - cnt;  // L[r0]
+    if (t < nd) {
+      for (int b = 0; b < 32; ++b) {
+        const int r = r0 + b;
+        if (r >= m || r >= r_hi) break;
+        L += ((w >> b) & 1u) ? 0 : 1;
+        rb[r + 1] = make_int2(L, 0);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 255) carry += part[255];
+    __syncthreads();
+  }
+}
+
+void bits_launch_border_to_bits(hipStream_t st, const int2* lb, int m, int r_lo, int r_hi, uint32_t* vbits) {
+  const int nd = (r_hi - r_lo + 31) / 32;
+  hipLaunchKernelGGL(border_to_bits, dim3(std::max(1, std::min((nd + 255) / 256, 256))), dim3(256), 0, st, lb, m, r_lo, r_hi, vbits);
+}
+void bits_launch_bits_to_border(hipStream_t st, const uint32_t* vbits, int m, int r_lo, int r_hi, int2* rb) {
+  hipLaunchKernelGGL(bits_to_border, dim3(1), dim3(256), 0, st, vbits, m, r_lo, r_hi, rb);
 }
 
 int bits_steps(int n) { return ((n + 63 * kBitsSkew + 63) / 64) * 64; }

@@ -68,6 +68,7 @@ struct sa_ctx {
   const uint8_t* dev_pool = nullptr;  // sa_batch_set_device_pool: the batch entry points read the sequences here
   int64_t dev_pool_bytes = 0;
   Buf lbuf, dpbuf, pbuf;
+  Buf vlb, vrb;  // bit-vector LCS over column stripes: the stripe's left / right border column as bits
   // geometry of the last fill, for the traceback that follows it
   struct {
     int valid = 0, kind = 0, m = 0, n = 0, K = 0, W = 0, first_stripe = 1;
@@ -690,6 +691,8 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
   HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
   if (persist) {
     const dim3 grid(grid_blocks);
+    if (!handoff_ring_ok(a.ring, S, grid_blocks * kWavesPerBlock))
+      return fail(ctx, SA_ERR_HIP, "internal: %d record slots for %d strips on %d waves", a.ring, S, grid_blocks * kWavesPerBlock);
     if (group)
       launch_group_kind(kind, K, grid, group_lds_bytes(alpha, PW), st, a, ckpt || no_tb, kind == KIND_NW && (fl & FLAG_FRAC) != 0);
     else
@@ -796,9 +799,18 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
 // per cell.  Applies when the pair holds at most 63 distinct bytes (DNA, proteins, text), the record (m n / 8 bytes)
 // fits the budget, and nothing asks for the cell-by-cell kernels (matrix dump, forced rows per lane, forced
 // checkpointing, column stripes).  *used = false: the caller takes fill_impl instead.  Events as in fill_impl.
-int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n, uint32_t flags, sa_result* out, bool* used) {
+int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n, uint32_t flags, sa_result* out, bool* used,
+                  const StripeDesc* sd = nullptr) {
   *used = false;
   if (!ctx->lcs_bits || !ctx->persist || ctx->force_K || ctx->force_band > 0 || (flags & SA_FLAG_KEEP_DP)) return SA_OK;
+  // Column stripes (round 3): the same kernel, the stripe's left border column as its first V and its last V as the right
+  // border; the borders travel as (H, E) rows as before and are converted on the transfer streams.  Needs the overlapped
+  // schedule (the kernel is persistent) and border chunks of whole strips.
+  const bool striped = sd && !(sd->is_first && sd->is_last);
+  const bool ev_in = sd && !sd->is_first, ev_out = sd && !sd->is_last;
+  const int64_t R = sd ? std::max<int64_t>(sd->chunk_rows, 1) : 0;
+  if (striped && ((ev_in && !(sd->on_event && sd->stream_in)) || (ev_out && !(sd->on_event && sd->stream_out)) || R % kBitsStripRows != 0)) return SA_OK;
+  const int64_t n_chunks = striped ? (m + R - 1) / R : 0;
   uint8_t lmap[256];
   bool seen[256] = {false};
   for (int i = 0; i < m; ++i) seen[x[i]] = true;
@@ -845,7 +857,10 @@ int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n,
   if ((rc = ensure(ctx, ctx->yenc, (size_t)Tend + 256))) return rc;
   if ((rc = ensure(ctx, ctx->bot, (size_t)2 * ring * NP * 4))) return rc;
   if ((rc = ensure(ctx, ctx->small, 256))) return rc;
-  if ((rc = ensure(ctx, ctx->pbuf, 256))) return rc;
+  const size_t pbuf_ints = (size_t)S + 64 + (size_t)n_chunks;  // [0] ticket, [32] rows_in, [34..35] wait ticks, [64 + S ..] chunk_done (as fill_impl)
+  if ((rc = ensure(ctx, ctx->pbuf, pbuf_ints * 4))) return rc;
+  if (ev_in && (rc = ensure(ctx, ctx->vlb, (size_t)S * 64 * 4))) return rc;
+  if (ev_out && (rc = ensure(ctx, ctx->vrb, (size_t)S * 64 * 4))) return rc;
   if ((rc = ensure(ctx, ctx->ops, ops_bytes_offset(m, n) + ((size_t)m + n) / 4 + 1024))) return rc;
   if ((rc = ensure(ctx, ctx->prof, (size_t)S * alpha * 64 * 4))) return rc;
   if (trace_bytes && (rc = ensure(ctx, ctx->trace, trace_bytes))) return rc;
@@ -862,7 +877,12 @@ int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n,
   // (init_row0_records writes column c at index c + 64)
   hipLaunchKernelGGL(init_row0_records, dim3(std::min((n + 255) / 256, 2048)), dim3(256), 0, st, bot2 + (kBitsRecord0 - 64), (const int*)nullptr, n, 0, 0);
   HIPCK(ctx, hipMemsetAsync(ctx->small.p, 0, 256, st));
-  HIPCK(ctx, hipMemsetAsync(ctx->pbuf.p, 0, 256, st));
+  HIPCK(ctx, hipMemsetAsync(ctx->pbuf.p, 0, pbuf_ints * 4, st));
+  if (ev_in) {
+    HIPCK(ctx, hipMemsetAsync(ctx->vlb.p, 0xff, (size_t)S * 64 * 4, st));  // rows beyond m: no vertical step
+    const int corner[2] = {0, 0};  // entry 0 of the caller's left border is the matrix' row 0 at this stripe's left edge
+    HIPCK(ctx, hipMemcpyAsync((void*)sd->left, corner, 8, hipMemcpyHostToDevice, st));
+  }
   bits_launch_profile(st, (const uint8_t*)ctx->xenc.p, m, alpha, S, (uint32_t*)ctx->prof.p);
   FillArgs a{};
   a.m = m;
@@ -885,8 +905,41 @@ int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n,
   a.s_last = S - 1;
   a.err = (int*)ctx->small.p + 40;
   a.spin_limit = 1 << 22;
+  if (ev_in) {
+    a.vleft = (const uint32_t*)ctx->vlb.p;
+    a.rows_in = (int*)ctx->pbuf.p + 32;
+    a.wait_ticks = (unsigned long long*)((int*)ctx->pbuf.p + 34);
+  }
+  if (ev_out) {
+    a.vright = (uint32_t*)ctx->vrb.p;
+    a.chunk_done = (int*)ctx->pbuf.p + 64 + S;
+    a.strips_per_chunk = (int)(R / kBitsStripRows);
+  }
+  if (a.rows_in || a.chunk_done) {  // the transfer streams may not touch the flags before they are reset
+    HIPCK(ctx, hipEventRecord(ctx->ev[4], st));
+    if (a.rows_in) HIPCK(ctx, hipStreamWaitEvent(sd->stream_in, ctx->ev[4], 0));
+    if (a.chunk_done) HIPCK(ctx, hipStreamWaitEvent(sd->stream_out, ctx->ev[4], 0));
+  }
   HIPCK(ctx, hipEventRecord(ctx->ev[1], st));
+  if (!handoff_ring_ok(a.ring, S, grid_blocks * wpb))
+    return fail(ctx, SA_ERR_HIP, "internal: %d record slots for %d strips on %d waves", a.ring, S, grid_blocks * wpb);
   bits_launch_fill(st, grid_blocks, wpb, a);
+  // border hand-offs, all enqueued now and resolved on the device while the fill runs (as in fill_impl), with the
+  // conversion between border rows and bits on the transfer streams
+  for (int64_t k = 0; k < n_chunks; ++k) {
+    const int r_lo = (int)(k * R), r_hi = (int)std::min<int64_t>(m, (k + 1) * R);
+    if (a.rows_in) {
+      if (sd->on_event(sd->user, SA_EV_NEED_LEFT, k)) return fail(ctx, SA_ERR_ARG, "stripe callback failed (need chunk %lld)", (long long)k);
+      bits_launch_border_to_bits(sd->stream_in, (const int2*)sd->left, m, r_lo, r_hi, (uint32_t*)ctx->vlb.p);
+      hipLaunchKernelGGL(stripe_signal, dim3(1), dim3(64), 0, sd->stream_in, (int*)a.rows_in, r_hi);
+    }
+    if (a.chunk_done) {
+      const int target = (int)(std::min<int64_t>(S, (k + 1) * a.strips_per_chunk) - k * a.strips_per_chunk);
+      hipLaunchKernelGGL(stripe_wait, dim3(1), dim3(64), 0, sd->stream_out, a.chunk_done + k, target, a.err, 1 << 22);
+      bits_launch_bits_to_border(sd->stream_out, (const uint32_t*)ctx->vrb.p, m, r_lo, r_hi, (int2*)sd->right);
+      if (sd->on_event(sd->user, SA_EV_RIGHT_READY, k)) return fail(ctx, SA_ERR_ARG, "stripe callback failed (ready chunk %lld)", (long long)k);
+    }
+  }
   HIPCK(ctx, hipGetLastError());
   HIPCK(ctx, hipEventRecord(ctx->ev[2], st));
   out->n_launches = 1;
@@ -898,7 +951,7 @@ int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n,
   ctx->last.n = n;
   ctx->last.K = kBitsRowsPerLane;
   ctx->last.W = Tend;
-  ctx->last.first_stripe = 1;
+  ctx->last.first_stripe = (!sd || sd->is_first) ? 1 : 0;
   ctx->last.ckpt = 0;
   ctx->last.band = S;
   ctx->last.S = S;
@@ -1199,7 +1252,9 @@ int run_stripe_fill(sa_ctx* ctx, int kind, const uint8_t* x, int64_t m64, const 
   sd.stream_out = (hipStream_t)d->stream_out;
   if ((sd.stream_in && sd.stream_in == ctx->stream) || (sd.stream_out && sd.stream_out == ctx->stream))
     return fail(ctx, SA_ERR_ARG, "stream_in / stream_out must differ from the ctx stream");
-  if ((rc = fill_impl(ctx, kind, x, m, y, n, sc, &sd, 0, out, rowb, colb))) return rc;
+  bool bits = false;
+  if (kind == KIND_LCS && (rc = lcs_bits_fill(ctx, x, m, y, n, 0, out, &bits, &sd))) return rc;
+  if (!bits && (rc = fill_impl(ctx, kind, x, m, y, n, sc, &sd, 0, out, rowb, colb))) return rc;
   int h_small[41] = {0};  // [0] score / SW stripe best, [2..3] SW end cell, [40] persistent-kernel error flag
   HIPCK(ctx, hipMemcpyAsync(h_small, ctx->small.p, sizeof h_small, hipMemcpyDeviceToHost, ctx->stream));
   HIPCK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1893,7 +1948,7 @@ int sa_release_workspace(sa_ctx* c) {
   if (!c) return SA_ERR_ARG;
   (void)hipSetDevice(c->device);
   for (Buf* b : {&c->xenc, &c->yenc, &c->prof, &c->sub, &c->colb, &c->bot, &c->state, &c->trace, &c->rowbest, &c->small,
-                 &c->ops, &c->b_seq, &c->b_desc, &c->b_out, &c->lbuf, &c->dpbuf, &c->pbuf})
+                 &c->ops, &c->b_seq, &c->b_desc, &c->b_out, &c->lbuf, &c->dpbuf, &c->pbuf, &c->vlb, &c->vrb})
     release(*b);
   for (HostBuf* h : {&c->h_desc, &c->h_out}) {
     if (h->p) (void)hipHostFree(h->p);

@@ -102,6 +102,18 @@ def main():
             if not good:
                 print(f"rank {rank}: MISMATCH {kind} n={n}: {r.score} vs {want.score}", flush=True)
             ok = ok and good
+    # LCS over stripes on the bit-vector kernel: border chunks of whole 2048-row strips (stripes.py's default is 8192)
+    if not expect_fallback:
+        al.chunk_rows = 2048
+        for n, seed, rel in [(20000, 5, True), (9000, 6, False)]:
+            x, y = dna_pair(n, seed=seed, related=rel)
+            r = al.align("lcs", x, y, "dna")
+            want = orc.lcs(x, y, packed=True)
+            good = r.score == want.score and r.rows_per_lane == 32 and (rank != 0 or np.array_equal(r.ops, want.ops))
+            if not good:
+                print(f"rank {rank}: MISMATCH bit-vector lcs n={n}: {r.score} vs {want.score}, rows per lane {r.rows_per_lane}", flush=True)
+            ok = ok and good
+        al.chunk_rows = 512
     if expect_fallback and not fell_back:
         print(f"rank {rank}: expected the overlapped schedule to time out with one hardware queue", flush=True)
         ok = False

@@ -34,7 +34,31 @@ class DevBuf:
         DevBuf.hip.hipFree(self.p)
 
 
-def striped(engine, kind, x, y, G, mode, go, ge, chunk_rows):
+class DevStreams:
+    """two HIP streams for the overlapped stripe schedule (stream_in / stream_out), synchronised between the replayed ranks"""
+
+    def __init__(self):
+        import ctypes as C
+
+        DevBuf(8).free()  # loads libamdhip64
+        self.hip = DevBuf.hip
+        self.hip.hipStreamCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+        self.hip.hipStreamDestroy.argtypes = [C.c_void_p]
+        self.s = [C.c_void_p(), C.c_void_p()]
+        for q in self.s:
+            assert self.hip.hipStreamCreate(C.byref(q)) == 0
+
+    def sync(self):
+        for q in self.s:
+            assert self.hip.hipStreamSynchronize(q) == 0
+
+    def close(self):
+        for q in self.s:
+            self.hip.hipStreamDestroy(q)
+
+
+def striped(engine, kind, x, y, G, mode, go, ge, chunk_rows, streams=None, options=None):
     xb = np.frombuffer(x.encode(), np.uint8)
     yb = np.frombuffer(y.encode(), np.uint8)
     m, n = len(xb), len(yb)
@@ -46,11 +70,18 @@ def striped(engine, kind, x, y, G, mode, go, ge, chunk_rows):
     import sequencealigner_amd as sa
 
     engs = [engine] + [sa.Engine(0) for _ in range(G - 1)]
+    for e in engs:
+        for name, value in (options or {}).items():
+            e.set_option(name, value)
     for g in range(G):
         left, right = borders[g], borders[g + 1]
         r = engs[g].stripe_fill(kind, xb, yb[bounds[g]:bounds[g + 1]], n, bounds[g], g == 0, g == G - 1,
                                 None if left is None else left.data_ptr(), None if right is None else right.data_ptr(),
-                                chunk_rows, lambda ev, k, g=g: events.append((g, ev, k)), mode, go, ge)
+                                chunk_rows, lambda ev, k, g=g: events.append((g, ev, k)), mode, go, ge,
+                                **({"stream_in": streams.s[0].value, "stream_out": streams.s[1].value} if streams else {}))
+        if streams:
+            streams.sync()  # the border conversions / signals of this rank are done before the next rank is replayed
+        striped.last_rows_per_lane = r.rows_per_lane
         if g == G - 1:
             score = r.score
     ops = []
@@ -90,6 +121,56 @@ def test_stripes_equal_single_gpu(engine, oracle, kind):
             assert need == (list(range(n_chunks)) if g > 0 else [])
             assert ready == (list(range(n_chunks)) if g < G - 1 else [])
     engine.set_tuning(0, 0)
+
+
+def lcs_bits_stripe_cases(engine, oracle):
+    """Overlapped schedule (transfer streams given) with border chunks of whole 2048-row strips: LCS stripes run
+    lcs_bits_persistent with the border column converted between (H, E) rows and vertical-difference bits on the
+    transfer streams; same score and op list as the oracle.  Ragged row counts, 2..5 stripes, related and unrelated."""
+    rng = np.random.default_rng(43)
+    st = DevStreams()
+    try:
+        for (m, n, G, R, rel) in [(5000, 5200, 2, 2048, True), (9001, 7000, 3, 4096, True), (4097, 9000, 5, 2048, False),
+                                  (20000, 20000, 4, 8192, True), (2048, 3000, 2, 2048, False), (100, 700, 2, 2048, True)]:
+            if rel:
+                x = rand_seq(rng, m, DNA)
+                y = mutate(rng, x, DNA)[:n]
+            else:
+                x, y = rand_seq(rng, m, DNA), rand_seq(rng, n, DNA)
+            want = oracle.lcs(x, y, packed=True)
+            score, ops, _ = striped(engine, "lcs", x, y, G, "dna", -5.0, -1.0, R, streams=st)
+            assert striped.last_rows_per_lane == 32, "the bit-vector kernel did not run"
+            assert score == want.score, (m, n, G, R)
+            assert np.array_equal(ops, want.ops), (m, n, G, R)
+        # chunks that are not whole strips, or the option off: the cell-by-cell kernels, same answer
+        x = rand_seq(rng, 6000, DNA)
+        y = mutate(rng, x, DNA)
+        want = oracle.lcs(x, y, packed=True)
+        score, ops, _ = striped(engine, "lcs", x, y, 3, "dna", -5.0, -1.0, 1024, streams=st)
+        assert striped.last_rows_per_lane != 32, striped.last_rows_per_lane
+        assert score == want.score, (score, want.score)
+        assert np.array_equal(ops, want.ops)
+        score, ops, _ = striped(engine, "lcs", x, y, 3, "dna", -5.0, -1.0, 2048, streams=st, options={"lcs_bits": 0})
+        assert striped.last_rows_per_lane != 32, striped.last_rows_per_lane
+        assert score == want.score, (score, want.score)
+        assert np.array_equal(ops, want.ops)
+    finally:
+        engine.set_option("lcs_bits", 1)
+        st.close()
+
+
+def test_lcs_stripes_run_the_bit_vector_kernel():
+    """lcs_bits_stripe_cases in a process of its own with 16 hardware queues (what bench.py sets for N > 1): the
+    transfer streams must not share a hardware queue with the stream of the persistent kernel that waits for them."""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="16")
+    p = subprocess.run([sys.executable, str(root / "tests" / "helpers" / "run_lcs_bits_stripes.py")], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "LCS_BITS_STRIPES_OK" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
 
 
 def striped_sw(engine, x, y, G, mode, go, ge, chunk_rows):
