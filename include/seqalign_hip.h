@@ -112,7 +112,10 @@ int sa_set_tuning(sa_ctx* ctx, int rows_per_lane, int tile_steps);
  * work, and e.g. 2 Mb x 2 Mb on one GPU), "checkpoint_band" N > 0 (always take that path, N strips per band),
  * "lcs_bits" 0/1 (default 1: sa_lcs on a whole pair over at most 63 distinct bytes runs as bit-vector
  * arithmetic -- 32 rows per lane, sa_result.rows_per_lane = 32, one bit of traceback record per cell; same
- * results as the cell-by-cell kernels, which still serve stripes, checkpointed runs, dumps and larger alphabets),
+ * results as the cell-by-cell kernels, which still serve checkpointed runs, dumps, larger alphabets and stripes whose
+ * border chunks are not whole 2048-row strips or that run the in-line schedule),
+ * "group" 0/1 (default 0: NW / SW fills of a whole matrix run fill_group -- four consecutive strips per workgroup, their
+ * bottom rows handed down through LDS -- instead of fill_persistent; same results, measured no faster: DESIGN.md 3.1c),
  * "lcs_bits_waves_per_block" 0 (automatic) / 1 / 2 / 4 (measurements: how many strips share a workgroup there),
  * "max_workgroups" N (0 = as many as the GPU holds: a persistent launch uses at most N workgroups of four waves;
  * tests use it to make small inputs take several rounds of strips per wave; same results) */

@@ -6,7 +6,4 @@ void launch_fill_nw(int K, int fl, dim3 grid, size_t lds, hipStream_t st, const 
 void launch_persistent_nw(int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a, bool notrace, bool lprof, bool frac) {
   launch_persistent<KIND_NW>(K, grid, lds, st, a, notrace, lprof, frac);
 }
-void launch_group_nw(int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a, bool notrace, bool frac) {
-  launch_group<KIND_NW>(K, grid, lds, st, a, notrace, frac);
-}
 }  // namespace sa

@@ -6,7 +6,4 @@ void launch_fill_sw(int K, int fl, dim3 grid, size_t lds, hipStream_t st, const 
 void launch_persistent_sw(int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a, bool notrace, bool lprof, bool frac) {
   launch_persistent<KIND_SW>(K, grid, lds, st, a, notrace, lprof, frac);
 }
-void launch_group_sw(int K, dim3 grid, size_t lds, hipStream_t st, const FillArgs& a, bool notrace, bool frac) {
-  launch_group<KIND_SW>(K, grid, lds, st, a, notrace, frac);
-}
 }  // namespace sa

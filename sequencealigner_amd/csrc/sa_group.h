@@ -142,6 +142,19 @@ __device__ __forceinline__ void run_block_g(Lane<KIND, K>& st, const FillArgs& a
       }
       lane_step<KIND, K, BND, FLAGS>(st, ibH, ibF, yb, obH, obF, tacc, u, ldsLane, xr, a, cbase + u, dprow, sbk, skp);
     }
+    if (BND && EdgeMode<KIND, FLAGS>::kMasked) {
+      // frozen lanes skipped their cells (lane_step): a row's parked key may still wait to be folded, and the codes of a
+      // lane that froze after `act` steps of this sub-block sit in the top 2 * act bits of its words instead of the bottom
+      if (KIND == KIND_SW) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) sbk[k] = max(sbk[k], skp[k]);
+      }
+      if (FLAGS & FLAG_TAIL) {
+        const int sh = 2 * (16 - min(max(a.n - cbase, 0), 16));  // 32 (no active step: the words are still 0) shifts by 0
+#pragma unroll
+        for (int k = 0; k < K; ++k) tacc[k] >>= (sh & 31);
+      }
+    }
     lds_write_word(gw.p_own, jn);  // sub-blocks 0 .. jn - 1 of this strip are in the ring
     if (KIND == KIND_SW) {
 #pragma unroll
@@ -283,6 +296,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock, 2) fill_group(const FillA
       const bool interior = (Tb >= 64) && (Tb + 63 < a.n);
       if (interior)
         run_block_g<KIND, K, false, PF>(st, a, s, Tb, lane, live, nowait, ldsLane, xr, dprow, gw, yb, ny, pend, ibH, ibF, obH, obF, rd, wr, wr_slot_base, gen_r, gen_w);
+      else if (b == 0 && a.n > 63)
+        run_block_g<KIND, K, true, PF | FLAG_START>(st, a, s, 0, lane, live, nowait, ldsLane, xr, dprow, gw, yb, ny, pend, ibH, ibF, obH, obF, rd, wr, wr_slot_base, gen_r, gen_w);
+      else if (b > 0)
+        run_block_g<KIND, K, true, PF | FLAG_TAIL>(st, a, s, Tb, lane, live, nowait, ldsLane, xr, dprow, gw, yb, ny, pend, ibH, ibF, obH, obF, rd, wr, wr_slot_base, gen_r, gen_w);
       else
         run_block_g<KIND, K, true, PF>(st, a, s, Tb, lane, live, nowait, ldsLane, xr, dprow, gw, yb, ny, pend, ibH, ibF, obH, obF, rd, wr, wr_slot_base, gen_r, gen_w);
     }

@@ -138,7 +138,20 @@ __device__ __forceinline__ int dpp_shl1_any(int src) { return __builtin_amdgcn_m
 
 // FLAG_LPROF (persistent LCS, at most 31 distinct bytes in the pair): the match term comes from an LDS profile
 // like the NW one (byte +6 on a match, -62 otherwise: one SDWA add) instead of a compare and a select per cell.
-enum { FLAG_FRAC = 1, FLAG_DUMP = 2, FLAG_PERSIST = 4, FLAG_NOTRACE = 8, FLAG_LPROF = 16 };
+// FLAG_START (with BND): the block is a strip's first one and the matrix has more than 63 columns, so the only lanes to
+// freeze are those that have not reached column 0 yet (no test against n).  The first block is on the critical path of
+// every chain of strips: the strip below starts once this strip's lane 63 has left it.
+// FLAG_TAIL (with BND): a block behind the first one, so the only lanes to freeze are those that have passed column n - 1.
+// The last blocks are on the critical path too: a strip can finish only 80 steps after the strip above it has.
+// NW / SW with one of the two: the cells of a frozen lane are not computed and thrown away by selects, they are skipped
+// (one divergent `if` around the K cells, i.e. an exec mask): kMaskedEdge.
+enum { FLAG_FRAC = 1, FLAG_DUMP = 2, FLAG_PERSIST = 4, FLAG_NOTRACE = 8, FLAG_LPROF = 16, FLAG_START = 32, FLAG_TAIL = 64 };
+template <int KIND, int FLAGS>
+struct EdgeMode {
+  // Measured (100 kb x 100 kb, K = 2): masked 14.2 ms against 13.0 with selects -- the branch around the cells cuts the
+  // compiler's profile prefetch at every step -- so it stays off; the code is kept for the record.
+  static constexpr bool kMasked = false && KIND != KIND_LCS && (FLAGS & (FLAG_START | FLAG_TAIL)) != 0 && !(FLAGS & FLAG_DUMP);
+};
 
 // Workgroups are 4 independent waves (256 threads): the hardware places the 4 waves of one
 // workgroup on the 4 SIMDs of a CU, which single-wave workgroups do not guarantee -- and a wave
@@ -231,87 +244,95 @@ __device__ __forceinline__ void lane_step(Lane<KIND, K>& st, int& ibH, int& ibF,
   int diag = st.dprev;
   st.dprev = up;
   st.ypass = yv;
-  const bool act = BND ? (c >= 0 && c < n) : true;
+  const bool act = BND ? ((FLAGS & FLAG_START) ? c >= 0 : ((FLAGS & FLAG_TAIL) ? c < n : (c >= 0 && c < n))) : true;
+  constexpr bool MASKED = BND && EdgeMode<KIND, FLAGS>::kMasked;  // frozen lanes skip the cells
+  constexpr bool SEL = BND && !MASKED;                            // frozen lanes compute and keep their old values by selects
   int f_last = 0;
   int upg = (KIND != KIND_LCS) ? add_gap<FRAC>(up, go, a.fo) : 0;  // (H + gap_open) of the cell above, tag 0
-#pragma unroll
-  for (int k = 0; k < K; ++k) {
-    const int left = st.H[k];
-    int h;
-    if (KIND == KIND_LCS) {
-      // Tagged like NW: registers hold 4 * L + 1 (the value as a LEFT candidate, tag 1); the cell above
-      // becomes the UP candidate with + 1 (tag 2) and the diagonal one, on a match, 4 * (L_diag + 1) + 3.
-      // A match always wins (L_diag + 1 >= L_up, L_left), a tie between up and left goes to up
-      // (main.cpp:1581), so one max3 yields value and direction: 7 ops per cell, no compare masks.
-      // a mismatch (diag - 62) can never reach `left` (L[i][j-1] >= L[i-1][j-1])
-      const int dc = LPROF ? diag + (int)(int8_t)(pw[k / 4] >> (8 * (k & 3))) : ((xr[k] == (uint32_t)yv) ? diag + 6 : 0);
-      const int ht = max(max(dc, up + 1), left);
-      tacc[k] = __builtin_amdgcn_alignbit((uint32_t)ht, tacc[k], 2);
-      if (K >= 16 && !(FLAGS & FLAG_NOTRACE)) asm volatile("" : "+v"(tacc[k]));  // pack now (as for SW below): 16 x 16 live maxima do not fit
-      // one v_and_or_b32; written as C the compiler splits it into an AND and two ORs per cell
-      asm("v_and_or_b32 %0, %1, -4, 1" : "=v"(h) : "v"(ht));
-      if (BND) h = act ? h : left;
-    } else {
-      // tagged candidates: see the header of this file
-      const int sg = (int)(int8_t)(pw[k / 4] >> (8 * (k & 3)));  // 4*sigma + 2
-      int f = max(upg, add_gap<FRAC>(uf, ge, a.fe));               // tag 0
-      int e = max(st.Hg[k], add_gap<FRAC>(st.E[k], ge, a.fe));     // tag 1
-      int mv = diag + sg;                                          // tag 2
-      if (KIND == KIND_SW) {
-        // E and F are floored individually because the floored values are carried forward
-        // (main.cpp:968-973); the floor of M only ever feeds the cell maximum, where the 'X' floor
-        // below (tag 3 beats every tagged value <= 2) subsumes it.
-        f = max(f, 0);
-        e = max(e, 1);
-      }
-      int ht = max(max(mv, e), f);
-      if (KIND == KIND_SW) ht = max(ht, 3);
-      tacc[k] = __builtin_amdgcn_alignbit((uint32_t)ht, tacc[k], 2);
-      // SW: pack the code here and now.  Left alone the compiler sinks all 16 x K packing ops to the
-      // end of the sub-block and keeps every cell's maximum alive until then, which for SW (row
-      // bests on top) no longer fits 256 VGPRs and turns into AGPR copies.
-      if (KIND == KIND_SW) asm volatile("" : "+v"(tacc[k]));
-      h = ht & ~3;
-      if (BND) {
-        e = act ? e : st.E[k];
-        f = act ? f : st.passF;
-        h = act ? h : left;
-      }
-      st.E[k] = e;
-      uf = f;
-      f_last = f;
-    }
-    if (KIND == KIND_SW) {
-      // first row-major maximum (main.cpp:1124-1127), two ops per cell: inside a 16-step sub-block a
-      // row keeps max over its cells of (h << 2) + (15 - u) -- larger score first, then the earlier
-      // column; run_block folds it into (best, bestc) with a strict compare once per sub-block.
-      // h = 4 * score < 2^29 (check_scoring), so the key stays below 2^31.
-      uint32_t key = ((uint32_t)h << 2) + (uint32_t)(15 - u);
-      if (BND) key = act ? key : 0u;
-      // Two steps share one v_max3_u32: the even step parks its key, the odd one folds both.  Here and now
-      // (the empty asm): left alone the compiler sinks all 16 x K key computations to the end of the
-      // sub-block and keeps every cell's value alive until then (spills once the four sub-blocks are in line).
-      if ((u & 1) == 0) {
-        skp[k] = key;
-        asm volatile("" : "+v"(skp[k]));
+  auto cells = [&]() {
+  #pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const int left = st.H[k];
+      int h;
+      if (KIND == KIND_LCS) {
+        // Tagged like NW: registers hold 4 * L + 1 (the value as a LEFT candidate, tag 1); the cell above
+        // becomes the UP candidate with + 1 (tag 2) and the diagonal one, on a match, 4 * (L_diag + 1) + 3.
+        // A match always wins (L_diag + 1 >= L_up, L_left), a tie between up and left goes to up
+        // (main.cpp:1581), so one max3 yields value and direction: 7 ops per cell, no compare masks.
+        // a mismatch (diag - 62) can never reach `left` (L[i][j-1] >= L[i-1][j-1])
+        const int dc = LPROF ? diag + (int)(int8_t)(pw[k / 4] >> (8 * (k & 3))) : ((xr[k] == (uint32_t)yv) ? diag + 6 : 0);
+        const int ht = max(max(dc, up + 1), left);
+        tacc[k] = __builtin_amdgcn_alignbit((uint32_t)ht, tacc[k], 2);
+        if (K >= 16 && !(FLAGS & FLAG_NOTRACE)) asm volatile("" : "+v"(tacc[k]));  // pack now (as for SW below): 16 x 16 live maxima do not fit
+        // one v_and_or_b32; written as C the compiler splits it into an AND and two ORs per cell
+        asm("v_and_or_b32 %0, %1, -4, 1" : "=v"(h) : "v"(ht));
+        if (SEL) h = act ? h : left;
       } else {
-        sbk[k] = max(max(sbk[k], skp[k]), key);
-        asm volatile("" : "+v"(sbk[k]));
+        // tagged candidates: see the header of this file
+        const int sg = (int)(int8_t)(pw[k / 4] >> (8 * (k & 3)));  // 4*sigma + 2
+        int f = max(upg, add_gap<FRAC>(uf, ge, a.fe));               // tag 0
+        int e = max(st.Hg[k], add_gap<FRAC>(st.E[k], ge, a.fe));     // tag 1
+        int mv = diag + sg;                                          // tag 2
+        if (KIND == KIND_SW) {
+          // E and F are floored individually because the floored values are carried forward
+          // (main.cpp:968-973); the floor of M only ever feeds the cell maximum, where the 'X' floor
+          // below (tag 3 beats every tagged value <= 2) subsumes it.
+          f = max(f, 0);
+          e = max(e, 1);
+        }
+        int ht = max(max(mv, e), f);
+        if (KIND == KIND_SW) ht = max(ht, 3);
+        tacc[k] = __builtin_amdgcn_alignbit((uint32_t)ht, tacc[k], 2);
+        // SW: pack the code here and now.  Left alone the compiler sinks all 16 x K packing ops to the
+        // end of the sub-block and keeps every cell's maximum alive until then, which for SW (row
+        // bests on top) no longer fits 256 VGPRs and turns into AGPR copies.
+        if (KIND == KIND_SW) asm volatile("" : "+v"(tacc[k]));
+        h = ht & ~3;
+        if (SEL) {  // a frozen lane keeps H and E of its rows (and passF, below); what it computes for F goes nowhere
+          e = act ? e : st.E[k];
+          h = act ? h : left;
+        }
+        st.E[k] = e;
+        uf = f;
+        f_last = f;
+      }
+      if (KIND == KIND_SW) {
+        // first row-major maximum (main.cpp:1124-1127), two ops per cell: inside a 16-step sub-block a
+        // row keeps max over its cells of (h << 2) + (15 - u) -- larger score first, then the earlier
+        // column; run_block folds it into (best, bestc) with a strict compare once per sub-block.
+        // h = 4 * score < 2^29 (check_scoring), so the key stays below 2^31.
+        uint32_t key = ((uint32_t)h << 2) + (uint32_t)(15 - u);
+        if (SEL) key = act ? key : 0u;
+        // Two steps share one v_max3_u32: the even step parks its key, the odd one folds both.  Here and now
+        // (the empty asm): left alone the compiler sinks all 16 x K key computations to the end of the
+        // sub-block and keeps every cell's value alive until then (spills once the four sub-blocks are in line).
+        if ((u & 1) == 0) {
+          skp[k] = key;
+          asm volatile("" : "+v"(skp[k]));
+        } else {
+          sbk[k] = max(max(sbk[k], skp[k]), key);
+          asm volatile("" : "+v"(sbk[k]));
+        }
+      }
+      if (DUMP) {
+        if (act && dprow[k] >= 0) a.dp[(size_t)dprow[k] + c + 1] = h >> 2;
+      }
+      diag = left;
+      st.H[k] = h;
+      up = h;
+      if (KIND != KIND_LCS) {
+        upg = add_gap<FRAC>(h, go, a.fo);
+        st.Hg[k] = upg + 1;  // tag 1: this value opens E of the next column
       }
     }
-    if (DUMP) {
-      if (act && dprow[k] >= 0) a.dp[(size_t)dprow[k] + c + 1] = h >> 2;
-    }
-    diag = left;
-    st.H[k] = h;
-    up = h;
-    if (KIND != KIND_LCS) {
-      upg = add_gap<FRAC>(h, go, a.fo);
-      st.Hg[k] = upg + 1;  // tag 1: this value opens E of the next column
-    }
+    st.passH = st.H[K - 1];
+    if (KIND != KIND_LCS) st.passF = SEL ? (act ? f_last : st.passF) : f_last;
+  };
+  if (MASKED) {
+    if (act) cells();
+  } else {
+    cells();
   }
-  st.passH = st.H[K - 1];
-  if (KIND != KIND_LCS) st.passF = BND ? (act ? f_last : st.passF) : f_last;
   obH = dpp_shl1(st.passH, obH);
   if (KIND != KIND_LCS) obF = dpp_shl1(st.passF, obF);
 }
@@ -633,6 +654,19 @@ __device__ __forceinline__ bool run_block_p(Lane<KIND, K>& st, const FillArgs& a
 #pragma unroll
     for (int u = 0; u < 16; ++u)
       lane_step<KIND, K, BND, FLAGS>(st, ibH, ibF, yb, obH, obF, tacc, u, ldsLane, xr, a, cbase + u, dprow, sbk, skp);
+    if (BND && EdgeMode<KIND, FLAGS>::kMasked) {
+      // frozen lanes skipped their cells (lane_step): a row's parked key may still wait to be folded, and the codes of a
+      // lane that froze after `act` steps of this sub-block sit in the top 2 * act bits of its words instead of the bottom
+      if (KIND == KIND_SW) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) sbk[k] = max(sbk[k], skp[k]);
+      }
+      if (FLAGS & FLAG_TAIL) {
+        const int sh = 2 * (16 - min(max(a.n - cbase, 0), 16));  // 32 (no active step: the words are still 0) shifts by 0
+#pragma unroll
+        for (int k = 0; k < K; ++k) tacc[k] >>= (sh & 31);
+      }
+    }
     if (KIND == KIND_SW) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
@@ -759,8 +793,15 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) fill_persistent(const Fil
       const int Tb = 64 * b;
       const int yb = YSCALE ? ny * G::ROWB : ny;
       const bool interior = (Tb >= 64) && (Tb + 63 < a.n);
-      const bool ok = interior ? run_block_p<KIND, K, false, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow, yb, ny, pend, ibH, ibF, obH, obF, rd, wr, wr_slot_base, gen_r, gen_w, dbgc)
-                               : run_block_p<KIND, K, true, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow, yb, ny, pend, ibH, ibF, obH, obF, rd, wr, wr_slot_base, gen_r, gen_w, dbgc);
+      bool ok;
+      if (interior)
+        ok = run_block_p<KIND, K, false, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow, yb, ny, pend, ibH, ibF, obH, obF, rd, wr, wr_slot_base, gen_r, gen_w, dbgc);
+      else if (b == 0 && a.n > 63)  // the strip's first block of a matrix that is wider than it (Tb = 0 as a literal)
+        ok = run_block_p<KIND, K, true, PF | FLAG_START>(st, a, s, 0, lane, ldsLane, xr, dprow, yb, ny, pend, ibH, ibF, obH, obF, rd, wr, wr_slot_base, gen_r, gen_w, dbgc);
+      else if (b > 0)               // the last blocks: every lane is past column 0
+        ok = run_block_p<KIND, K, true, PF | FLAG_TAIL>(st, a, s, Tb, lane, ldsLane, xr, dprow, yb, ny, pend, ibH, ibF, obH, obF, rd, wr, wr_slot_base, gen_r, gen_w, dbgc);
+      else
+        ok = run_block_p<KIND, K, true, PF>(st, a, s, Tb, lane, ldsLane, xr, dprow, yb, ny, pend, ibH, ibF, obH, obF, rd, wr, wr_slot_base, gen_r, gen_w, dbgc);
       dead = !ok;
     }
 #ifdef SA_DEBUG_HANDOFF
