@@ -288,7 +288,7 @@ def bench_batch(args, rank, local_rank, world, dist, torch, workload=None, neste
                          "peak": VALU_PEAK_TOPS, "unit": "T int32 lane-ops/s",
                          "frac": round(achieved / VALU_PEAK_TOPS, 4),
                          "traffic": batch_pmc_traffic(workload, per_rank), "traffic_note": "HBM bytes per step (all launches of one call) from the PMC passes in "
-                         "profiles/r02_batch_pmc.json (WRITE_SIZE + 2 x FETCH_SIZE); algorithmic: the sequences once (m + n bytes per pair) + 44 B of descriptor / result per pair",
+                         "profiles/r03_batch_pmc.json (WRITE_SIZE + 2 x FETCH_SIZE); algorithmic: the sequences once (m + n bytes per pair) + 44 B of descriptor / result per pair",
                          "kernel": kname, "ops_per_cell": ops},
         }
         if not args.no_cpu and world == 1:
@@ -333,7 +333,7 @@ def bench_batch(args, rank, local_rank, world, dist, torch, workload=None, neste
 
 def lcs_pmc_traffic(m, n):
     """Measured HBM bytes per launch of the bit-vector LCS kernel, from the committed PMC summary (1 Mb pair only)."""
-    f = ROOT / "profiles" / "r02_lcs1m_pmc.json"
+    f = ROOT / "profiles" / "r03_lcs1m_pmc.json"
     if not (f.exists() and m == 1_000_000):
         return None
     try:
@@ -343,10 +343,10 @@ def lcs_pmc_traffic(m, n):
 
 
 def batch_pmc_traffic(workload, per_rank):
-    """HBM bytes per call of the batch kernels from the committed PMC passes (profiles/r02_batch_pmc.json), scaled
+    """HBM bytes per call of the batch kernels from the committed PMC passes (profiles/r03_batch_pmc.json), scaled
     by the number of pairs (the traffic is per pair: sequences in, descriptors in, results out); null when there
     is no profile for the workload."""
-    f = Path(__file__).resolve().parent / "profiles" / "r02_batch_pmc.json"
+    f = Path(__file__).resolve().parent / "profiles" / "r03_batch_pmc.json"
     if not f.exists():
         return None
     d = json.loads(f.read_text()).get(workload)
@@ -358,10 +358,10 @@ def batch_pmc_traffic(workload, per_rank):
 def pmc_traffic(args, m, n, world, res):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 cannot
     run inside the timed program): WRITE_SIZE + 2 x FETCH_SIZE (gfx950 correction), valid for the
-    workload and schedule the profile was taken on (tools/profile_r02.sh), else null."""
-    tag = {(1000000, 999747): "1m", (100000, 100085): "100k"}.get((m, n))
-    f = Path(__file__).resolve().parent / "profiles" / f"r02_nw{tag}_pmc.json"
-    if world != 1 or args.kind != "nw" or args.unrelated or tag is None or res.n_launches != 1 or not f.exists():
+    workload and schedule the profile was taken on (tools/profile_r03.sh), else null."""
+    tag = {("nw", 1000000, 999747): "nw1m", ("nw", 100000, 100085): "nw100k", ("sw", 1000000, 999747): "sw1m"}.get((args.kind, m, n))
+    f = Path(__file__).resolve().parent / "profiles" / f"r03_{tag}_pmc.json"
+    if world != 1 or args.unrelated or tag is None or res.n_launches != 1 or not f.exists():
         return None
     return json.loads(f.read_text())["derived"]["hbm_traffic_bytes_per_launch"]
 
@@ -634,7 +634,7 @@ def main():
             line["roofline"] = {
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "traffic": lcs_pmc_traffic(m, n), "kernel": "lcs_bits_persistent", "bytes_per_cell": 0.125, "bytes_per_launch": rec_bytes,
-                "traffic_note": "HBM bytes per launch, WRITE_SIZE + 2 x FETCH_SIZE of the PMC passes in profiles/r02_lcs1m_pmc.json (that workload only)",
+                "traffic_note": "HBM bytes per launch, WRITE_SIZE + 2 x FETCH_SIZE of the PMC passes in profiles/r03_lcs1m_pmc.json (that workload only)",
                 "avg_launch_us": round(kernel_ms * 1e3 / max(launches, 1), 2),
                 "ns_per_column_step": round(kernel_ms * 1e6 / max(launches, 1) / steps_per_strip, 1),
                 "note": "the only HBM traffic of any size is the write-once traceback record (1 bit per cell).  The kernel does not reach the "

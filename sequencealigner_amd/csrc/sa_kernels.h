@@ -1193,7 +1193,8 @@ __device__ __forceinline__ uint32_t bits_word(const TraceArgs& a, int g, int c) 
   const int sidx = g >> 6, l = g & 63;
   // the strip's base is scalar in the window loads (g is wave-uniform there); inside a strip 32-bit dword indices do
   // (W * 64 < 2^32: the host refuses longer targets), so the loads are scalar base + 32-bit lane offset
-  const uint32_t* sb = a.trace + (size_t)sidx * ((size_t)a.W * 64 + kBitsStripPad);
+  // (banded recomputation: `trace` holds the strips from row i_min on, 2048 rows each)
+  const uint32_t* sb = a.trace + (size_t)(sidx - (a.i_min >> 11)) * ((size_t)a.W * 64 + kBitsStripPad);
   const uint32_t t = (uint32_t)(c + kBitsSkew * l);
   return sb[((t & ~3u) << 6) + (uint32_t)(l * 4) + (t & 3u)];
 }
@@ -1213,7 +1214,8 @@ struct BitsWindow {
 };
 __device__ __forceinline__ BitsWindow load_bits_window(const TraceArgs& a, int i, int j0, int q) {
   const int g0 = (i - 64) >> 5;
-  const int glast = ((a.m + 2047) / 2048) * 64 - 1;
+  // the last word the record holds: the walk's entry row bounds it (a band's record ends with the entry row's strip)
+  const int glast = (((a.start_i >= 0 ? a.start_i : a.m) + 2047) / 2048) * 64 - 1;
   const int g1 = g0 + 1, g2 = min(g0 + 2, glast);
   const int cA = j0 - 80 + q, cB = min(j0 - 16 + q, a.n - 1);
   BitsWindow w;
@@ -1290,7 +1292,7 @@ __device__ __forceinline__ void walk_rounds_bits(const uint32_t dm_lo, const uin
       : "scc", "vcc", "memory");
 }
 
-// BITS: the bit-vector LCS format above instead of 2-bit codes (whole matrix only: no bands, no stripes)
+// BITS: the bit-vector LCS format above instead of 2-bit codes (bands: the record starts with row i_min's strip)
 template <bool BITS>
 __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
   // The packed moves are staged in LDS and written out in bulk: with no global stores inside the walk, the

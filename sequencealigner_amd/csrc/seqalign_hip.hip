@@ -802,7 +802,8 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
 int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n, uint32_t flags, sa_result* out, bool* used,
                   const StripeDesc* sd = nullptr) {
   *used = false;
-  if (!ctx->lcs_bits || !ctx->persist || ctx->force_K || ctx->force_band > 0 || (flags & SA_FLAG_KEEP_DP)) return SA_OK;
+  if (!ctx->lcs_bits || !ctx->persist || ctx->force_K || (flags & SA_FLAG_KEEP_DP)) return SA_OK;
+  if (ctx->force_band > 0 && sd) return SA_OK;
   // Column stripes (round 3): the same kernel, the stripe's left border column as its first V and its last V as the right
   // border; the borders travel as (H, E) rows as before and are converted on the transfer streams.  Needs the overlapped
   // schedule (the kernel is persistent) and border chunks of whole strips.
@@ -840,14 +841,31 @@ int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n,
   const int cap = persist_wg_cap(ctx);
   const int wpb = ctx->bits_wpb ? ctx->bits_wpb : (S <= 2 * cap ? 2 : kWavesPerBlock);  // (single-wave workgroups are not guaranteed a SIMD of their own)
   const int grid_blocks = std::min((S + wpb - 1) / wpb, cap);
-  const int ring = std::min(S + 1, grid_blocks * wpb + 2);
   const size_t rows_pad = (size_t)S * kBitsStripRows;
-  // the record, the hand-off ring and the small buffers must fit the budget together; else the cell kernels (which checkpoint)
-  if (trace_bytes + (size_t)2 * ring * NP * 4 + (size_t)S * alpha * 64 * 4 + 2 * ((size_t)m + n) + rows_pad + (size_t)Tend + ((size_t)4 << 20) > budget) return SA_OK;
+  const size_t strip_rec_bytes = ((size_t)Tend * 64 + kBitsStripPad) * 4;
+  const size_t other_bytes = (size_t)S * alpha * 64 * 4 + 2 * ((size_t)m + n) + rows_pad + (size_t)Tend + ((size_t)4 << 20);
+  int ring = std::min(S + 1, grid_blocks * wpb + 2);
+  // Round 3: a record beyond the budget (2 Mb x 2 Mb: 500 GB) no longer sends the pair to the cell-by-cell kernels.  As
+  // there (fill_impl), the fill keeps the carry records of EVERY strip instead (ring = S + 1 slots, 8 B per column per
+  // strip: 16 GB at 2 Mb x 2 Mb) and writes no record; the traceback recomputes `band` strips at a time WITH their record
+  // (every strip starts from the all-ones column 0, so the kept carries are all a band needs) and walks them.
+  const bool ckpt = !no_tb && !sd && (trace_bytes + (size_t)2 * ring * NP * 4 + other_bytes > budget || ctx->force_band > 0);
+  int band = S;
+  size_t trace_alloc = trace_bytes;
+  if (ckpt) {
+    ring = S + 1;
+    const size_t ck_bytes = (size_t)2 * ring * NP * 4 + other_bytes;
+    if (ck_bytes + strip_rec_bytes > budget) return SA_OK;  // not even one strip's record beside the carries: the cell kernels' problem
+    band = (int)std::max<size_t>(1, std::min<size_t>((size_t)S, (budget - ck_bytes) / strip_rec_bytes));
+    if (ctx->force_band > 0) band = std::min(band, ctx->force_band);
+    trace_alloc = (size_t)band * strip_rec_bytes;
+  } else if (trace_bytes + (size_t)2 * ring * NP * 4 + other_bytes > budget) {
+    return SA_OK;  // (score-only calls and stripes never get here: no record / a stripe's record is its own problem)
+  }
   int rc;
   {
     const size_t need_bot = (size_t)2 * ring * NP * 4;
-    if (need_bot > ctx->bot.cap || trace_bytes > ctx->trace.cap) {
+    if (need_bot > ctx->bot.cap || trace_alloc > ctx->trace.cap) {
       release(ctx->bot);
       release(ctx->trace);
       release(ctx->dpbuf);
@@ -863,7 +881,7 @@ int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n,
   if (ev_out && (rc = ensure(ctx, ctx->vrb, (size_t)S * 64 * 4))) return rc;
   if ((rc = ensure(ctx, ctx->ops, ops_bytes_offset(m, n) + ((size_t)m + n) / 4 + 1024))) return rc;
   if ((rc = ensure(ctx, ctx->prof, (size_t)S * alpha * 64 * 4))) return rc;
-  if (trace_bytes && (rc = ensure(ctx, ctx->trace, trace_bytes))) return rc;
+  if (trace_alloc && (rc = ensure(ctx, ctx->trace, trace_alloc))) return rc;
   std::vector<uint8_t> xe(rows_pad + 64, 0), ye((size_t)Tend + 256, (uint8_t)(alpha - 1));
   for (int i = 0; i < m; ++i) xe[i] = lmap[x[i]];
   for (int j = 0; j < n; ++j) ye[j] = lmap[y[j]];
@@ -897,7 +915,7 @@ int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n,
   a.xpad = (const uint8_t*)ctx->xenc.p;
   a.bot2 = bot2;
   a.ring = ring;
-  a.trace = no_tb ? nullptr : (uint32_t*)ctx->trace.p;
+  a.trace = (no_tb || ckpt) ? nullptr : (uint32_t*)ctx->trace.p;  // checkpoint pass: no record
   a.trace_s0 = 0;
   a.score_out = (int*)ctx->small.p;
   a.ticket = (int*)ctx->pbuf.p;
@@ -952,11 +970,11 @@ int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n,
   ctx->last.K = kBitsRowsPerLane;
   ctx->last.W = Tend;
   ctx->last.first_stripe = (!sd || sd->is_first) ? 1 : 0;
-  ctx->last.ckpt = 0;
-  ctx->last.band = S;
+  ctx->last.ckpt = ckpt ? 1 : 0;
+  ctx->last.band = band;
   ctx->last.S = S;
   ctx->last.args = a;
-  ctx->last.lds = 0;
+  ctx->last.lds = (size_t)wpb;  // bit-vector LCS: the waves per workgroup of the launch (the band launches of a checkpointed run repeat it)
   ctx->last.lprof = 0;
   ctx->last.bits = 1;
   (a.trace ? out->cells_trace : out->cells_notrace) = (int64_t)m * n;
@@ -1004,7 +1022,13 @@ int traceback_ckpt(sa_ctx* ctx, int start_i, int start_j, sa_result* out) {
     a.trace_s0 = s_lo;
     const dim3 grid(std::min((s_hi - s_lo + 1 + kWavesPerBlock - 1) / kWavesPerBlock, persist_wg_cap(ctx)));
     HIPCK(ctx, hipEventRecord(ctx->ev[5], st));
-    launch_persistent_kind(kind, K, grid, ctx->last.lds, st, a, false, kind == KIND_LCS && ctx->last.lprof != 0, kind == KIND_NW && (a.fo != 0 || a.fe != 0));
+    if (ctx->last.bits) {  // the bit-vector LCS: the band's strips again, this time with their record; the score stays the first pass's
+      const int wpb = (int)ctx->last.lds;
+      a.score_out = (int*)ctx->small.p + 48;
+      bits_launch_fill(st, std::min((s_hi - s_lo + 1 + wpb - 1) / wpb, persist_wg_cap(ctx)), wpb, a);
+    } else {
+      launch_persistent_kind(kind, K, grid, ctx->last.lds, st, a, false, kind == KIND_LCS && ctx->last.lprof != 0, kind == KIND_NW && (a.fo != 0 || a.fe != 0));
+    }
     HIPCK(ctx, hipEventRecord(ctx->ev[6], st));
     ++out->n_launches;
     out->cells_trace += (int64_t)(std::min<int64_t>(m, (int64_t)(s_hi + 1) * 64 * K) - (int64_t)s_lo * 64 * K) * n;
@@ -1024,7 +1048,13 @@ int traceback_ckpt(sa_ctx* ctx, int start_i, int start_j, sa_result* out) {
     t.sw_pos = (const unsigned long long*)((char*)ctx->small.p + 8);
     t.ops2 = (unsigned long long*)((char*)ctx->ops.p + ops_bytes_offset(m, n));
     t.hdr = d_hdr;
-    hipLaunchKernelGGL(traceback_walk<false>, dim3(1), dim3(64), 0, st, t);
+    if (ctx->last.bits) {
+      t.xs = (const uint8_t*)ctx->xenc.p;
+      t.ys = (const uint8_t*)ctx->yenc.p;
+      bits_launch_traceback(st, t);
+    } else {
+      hipLaunchKernelGGL(traceback_walk<false>, dim3(1), dim3(64), 0, st, t);
+    }
     HIPCK(ctx, hipGetLastError());
     long long h_hdr[5] = {0, 0, 0, 0, 0};
     int h_err = 0;

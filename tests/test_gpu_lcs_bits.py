@@ -112,3 +112,42 @@ def test_bits_waves_per_workgroup(engine, oracle):
             assert g.rows_per_lane == 32 and g.score == o.score and np.array_equal(g.ops, o.ops), wpb
     finally:
         engine.set_option("lcs_bits_waves_per_block", 0)
+
+
+def test_bits_checkpointed_bands(engine, oracle):
+    """A record that does not fit: the fill keeps every strip's carry records and no record, the traceback runs the
+    strips again `checkpoint_band` at a time with their record (forced here; at 2 Mb x 2 Mb the engine does it by itself,
+    tests/test_gpu_z_fullsize.py).  Same score and op list; band edges at every strip boundary, paths that cross several
+    bands, leave through row 0 or column 0, and start in a ragged last strip."""
+    from sequencealigner_amd.synth import dna_pair
+
+    rng = np.random.default_rng(3205)
+    try:
+        for (m, n, band) in [(700, 900, 1), (2048, 2048, 1), (2049, 2047, 1), (4096, 4100, 1), (4097, 300, 1), (300, 9000, 1), (9000, 300, 2),
+                             (6145, 6100, 2), (12000, 11000, 3), (12000, 11000, 1), (5000, 5100, 1000)]:
+            engine.set_option("checkpoint_band", band)
+            for alphabet in (DNA, "AC"):
+                g = check("lcs", engine, oracle, rand_seq(rng, m, alphabet), rand_seq(rng, n, alphabet), "dna")
+                assert g.rows_per_lane == 32 and 2 <= g.n_launches <= 1 + -(-((m + 2047) // 2048) // band), (m, n, band, g.n_launches)
+            x = rand_seq(rng, m, DNA)
+            g = check("lcs", engine, oracle, x, mutate(rng, x, DNA, 0.1, 0.03, 0.03), "dna")
+            assert g.rows_per_lane == 32 and g.n_launches >= 2
+        engine.set_option("checkpoint_band", 2)
+        for x, y in [("A" * 5000, "A" * 4570), ("AC" * 3000, "CA" * 2800), ("A" * 5000, "C" * 4000), ("A" * 2048 + "C" * 2048, "C" * 2048 + "A" * 2048)]:
+            g = check("lcs", engine, oracle, x, y, "dna")
+            assert g.rows_per_lane == 32 and g.n_launches >= 2
+        engine.set_option("checkpoint_band", 3)
+        for related in (True, False):
+            x, y = dna_pair(40000, seed=31, related=related)
+            o, g = oracle.lcs(x, y, packed=True), engine.lcs(x, y)
+            assert g.rows_per_lane == 32 and g.n_launches == 1 + 7 and g.score == o.score and np.array_equal(g.ops, o.ops), related
+        # the score-only call has nothing to recompute
+        import sequencealigner_amd.engine as sa
+
+        g = engine.lcs(x, y, flags=sa.SA_FLAG_NO_TRACEBACK)
+        assert g.rows_per_lane == 32 and g.n_launches == 1 and g.score == o.score
+    finally:
+        engine.set_option("checkpoint_band", 0)
+    # and the one-slab run afterwards is the old one
+    g = engine.lcs(x, y)
+    assert g.n_launches == 1 and g.score == o.score and np.array_equal(g.ops, o.ops)

@@ -70,6 +70,15 @@ def test_lcs_1mb_equals_banded_oracle(engine, oracle, pair_1mb):
     engine.set_option("persistent", 0)
     b = engine.lcs(x, y)
     assert b.score == a.score and np.array_equal(a.ops, b.ops)
+    # the bit-vector kernel with its record recomputed 150 strips (of 2048 rows) at a time
+    engine.set_option("persistent", 1)
+    engine.set_option("checkpoint_band", 150)
+    try:
+        b = engine.lcs(x, y)
+    finally:
+        engine.set_option("checkpoint_band", 0)
+    assert b.rows_per_lane == 32 and b.n_launches == 1 + 4  # 489 strips
+    assert b.score == a.score and np.array_equal(a.ops, b.ops)
 
 
 def test_nw_1mb_checkpointed_bands_equal_banded_oracle(engine, nw_1mb_want, pair_1mb):
@@ -141,4 +150,13 @@ def test_nw_2mb_beyond_device_memory(engine, oracle):
     assert want.rc == 0 and touched == 0
     assert a.score == want.score
     assert len(a.ops) == len(want.ops) and np.array_equal(a.ops, want.ops)
+    # LCS of the same pair: the one-bit-per-cell record is 500 GB; the bit-vector kernel keeps its carry records (16 GB)
+    # and recomputes the record in bands
+    engine.release_workspace()
+    b = engine.lcs(x, y)
+    assert b.rows_per_lane == 32 and b.n_launches >= 3
+    want, touched = oracle.lcs_banded(x, y, 1024)
+    assert want.rc == 0 and touched == 0
+    assert b.score == want.score
+    assert len(b.ops) == len(want.ops) and np.array_equal(b.ops, want.ops)
     engine.release_workspace()

@@ -1,5 +1,5 @@
 """Randomised GPU-vs-oracle parity: shapes, alphabets, gap settings, rows per lane, both fill
-schedules, checkpoint bands, score-only calls, bit-vector / cell-by-cell LCS.  `python tools/fuzz_gpu.py SECONDS [SEED]`; prints a
+schedules, fill_group, few workgroups (several rounds of tickets), checkpoint bands, score-only calls, bit-vector / cell-by-cell LCS.  `python tools/fuzz_gpu.py SECONDS [SEED]`; prints a
 line per 200 cases and stops at the first mismatch with the reproducer."""
 import sys
 import time
@@ -45,6 +45,9 @@ while time.time() - t0 < budget:
     eng.set_option("persistent", persistent)
     eng.set_option("checkpoint_band", band)
     eng.set_option("lcs_bits", int(rng.random() < 0.85))
+    group = int(rng.random() < 0.4)
+    eng.set_option("group", group)  # fill_group instead of fill_persistent (NW / SW, persistent schedule)
+    eng.set_option("max_workgroups", int(rng.choice([0, 0, 0, 1, 2, 7])))
     if kind == "lcs":
         g, o = eng.lcs(x, y, flags=flags), orc.lcs(x, y)
     else:
@@ -54,7 +57,7 @@ while time.time() - t0 < budget:
         ok = ok and tuple(g.start) == tuple(o.start) and np.array_equal(g.ops, o.ops)
     n_cases += 1
     if not ok:
-        print(f"MISMATCH case {n_cases}: kind={kind} mode={mode} m={len(x)} n={len(y)} go={go} ge={ge} K={K} persistent={persistent} "
+        print(f"MISMATCH case {n_cases}: kind={kind} mode={mode} m={len(x)} n={len(y)} go={go} ge={ge} K={K} persistent={persistent} group={group} "
               f"band={band} flags={flags} seed={seed}: gpu score {g.score} end {g.end} vs oracle {o.score} {o.end}", flush=True)
         Path(ROOT / "gpurun_out").mkdir(exist_ok=True)
         (ROOT / "gpurun_out" / "fuzz_fail.txt").write_text(f"{kind}\n{mode}\n{go} {ge} {K} {persistent} {band} {flags}\n{x}\n{y}\n")
