@@ -629,8 +629,11 @@ def main():
             # bit-vector LCS (sa_lcsbits.hip): 3 integer operations per 32 cells, one bit of traceback record per cell;
             # what it moves is the record, S x steps x 256 bytes per launch (m n / 8 + padding)
             strips, steps_per_strip = (m + 2047) // 2048, ((n + 126 + 63) // 64) * 64
-            rec_bytes = strips * steps_per_strip * 256 * (1 if cells_trace else 0)
-            gbs = rec_bytes * args.steps / k_s / 1e9
+            # (a checkpointed run: the first pass writes no record, the bands write the record of the rows they cover; all
+            # launches are inside kernel_ms, so `achieved` is the record written by all of them over the time of all of them)
+            rec_step = int(strips * steps_per_strip * 256 * (cells_trace / args.steps / (m * n)))
+            rec_bytes = rec_step // max(launches // args.steps, 1)
+            gbs = rec_step * args.steps / k_s / 1e9
             line["roofline"] = {
                 "bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
                 "traffic": lcs_pmc_traffic(m, n), "kernel": "lcs_bits_persistent", "bytes_per_cell": 0.125, "bytes_per_launch": rec_bytes,

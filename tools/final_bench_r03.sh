@@ -21,7 +21,8 @@ run nw1m_unrelated 200 --no-batch --unrelated --no-cpu || exit 1
 run lcs1m 200 --kind lcs --no-batch || exit 1
 run lcs100k 120 --kind lcs --size 100000 --steps 5 --no-batch || exit 1
 run sw1m 200 --kind sw --no-batch || exit 1
-run nw2m_checkpointed 300 --size 2000000 --steps 1 --warmup 0 --no-batch --no-cpu || exit 1
+run nw2m_checkpointed 300 --size 2000000 --steps 1 --warmup 1 --no-batch --no-cpu --no-small || exit 1   # (warm: the first call allocates 250 GB, 5 s)
+run lcs2m_checkpointed 300 --kind lcs --size 2000000 --steps 2 --warmup 1 --no-batch --no-cpu --no-small || exit 1
 run batch_align 200 --workload batch-align || exit 1
 run batch_global 200 --workload batch-global || exit 1
 cat "$OUT/status.txt"
