@@ -110,9 +110,9 @@ int sa_set_tuning(sa_ctx* ctx, int rows_per_lane, int tile_steps);
  * whose codes exceed it is filled with checkpoints -- the bottom row of every strip -- and the
  * traceback recomputes the strips it crosses, a band at a time: same results, about twice the fill
  * work, and e.g. 2 Mb x 2 Mb on one GPU), "checkpoint_band" N > 0 (always take that path, N strips per band),
- * "lcs_bits" 0/1 (default 1: sa_lcs on a whole pair over at most 63 distinct bytes runs as bit-vector
+ * "lcs_bits" 0/1 (default 1: sa_lcs on a whole pair over at most 255 distinct bytes runs as bit-vector
  * arithmetic -- 32 rows per lane, sa_result.rows_per_lane = 32, one bit of traceback record per cell; same
- * results as the cell-by-cell kernels, which still serve checkpointed runs, dumps, larger alphabets and stripes whose
+ * results as the cell-by-cell kernels, which still serve dumps, pairs that hold all 256 byte values and stripes whose
  * border chunks are not whole 2048-row strips or that run the in-line schedule),
  * "group" 0/1 (default 0: NW / SW fills of a whole matrix run fill_group -- four consecutive strips per workgroup, their
  * bottom rows handed down through LDS -- instead of fill_persistent; same results, measured no faster: DESIGN.md 3.1c),

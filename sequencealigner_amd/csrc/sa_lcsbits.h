@@ -10,7 +10,8 @@ constexpr int kBitsRowsPerLane = 32;                      // one dword of vertic
 constexpr int kBitsStripRows = 64 * kBitsRowsPerLane;     // 2048 rows per strip (wavefront)
 constexpr int kBitsSub = 32;                              // steps between record hand-offs (16 or 32)
 constexpr int kBitsRecord0 = 256;                         // index of column 0 in a slot of hand-off records
-constexpr int kBitsMaxAlpha = 64;                         // profile symbols incl. the padding symbol: 16 KB of LDS per wave
+constexpr int kBitsMaxAlpha = 256;                        // profile symbols incl. the padding symbol (codes are bytes): 256 B of LDS each per wave
+constexpr int kBitsLdsBytes = 160 * 1024;                 // LDS of a CU (gfx950); a workgroup's waves share it
 
 // prof[s][sym][lane] = the rows (bit b = row (s * 64 + lane) * 32 + b) whose symbol is `sym`
 void bits_launch_profile(hipStream_t st, const uint8_t* xs, int m, int alpha, int S, uint32_t* prof);

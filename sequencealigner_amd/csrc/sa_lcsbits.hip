@@ -348,6 +348,10 @@ void bits_launch_profile(hipStream_t st, const uint8_t* xs, int m, int alpha, in
 
 void bits_launch_fill(hipStream_t st, int grid_blocks, int waves_per_block, const FillArgs& a) {
   const size_t lds = (size_t)a.alpha * 64 * 4 * waves_per_block;
+  if (lds > 64 * 1024) {  // beyond the default limit of dynamic LDS (alphabets of more than 127 / 63 symbols at two / four waves)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lcs_bits_persistent<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kBitsLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&lcs_bits_persistent<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kBitsLdsBytes);
+  }
   if (a.trace)
     hipLaunchKernelGGL(lcs_bits_persistent<true>, dim3(grid_blocks), dim3(64 * waves_per_block), lds, st, a);
   else

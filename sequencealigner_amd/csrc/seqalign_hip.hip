@@ -54,7 +54,7 @@ struct sa_ctx {
   size_t batch_trace_budget = (size_t)32 << 30;  // sa_sw_batch_align: device bytes of direction codes per chunk
   int persist = 1;  // 1: persistent strip pipeline (one launch) where it applies
   int bits_wpb = 0; // bit-vector LCS: waves per workgroup, 0 = automatic (option "lcs_bits_waves_per_block", for measurements)
-  int lcs_bits = 1; // 1: LCS of a whole pair over at most 63 distinct bytes runs as bit-vector arithmetic (sa_lcsbits.hip)
+  int lcs_bits = 1; // 1: LCS of a whole pair over at most 255 distinct bytes runs as bit-vector arithmetic (sa_lcsbits.hip)
   int wps = 1;      // persistent kernel: waves per SIMD to launch
   int group = 0;    // 1: NW / SW fills of a whole matrix run fill_group (sa_group.h: four strips per workgroup, LDS hand-offs)
   int max_wg = 0;   // persistent kernels: at most this many workgroups per launch (0: as many as the GPU holds); tests use it to
@@ -796,9 +796,9 @@ int fill_impl(sa_ctx* ctx, int kind, const uint8_t* x, int m, const uint8_t* y, 
 }
 
 // LCS of one whole pair as bit-vector arithmetic (sa_lcsbits.hip): 32 rows per lane and one bit of traceback record
-// per cell.  Applies when the pair holds at most 63 distinct bytes (DNA, proteins, text), the record (m n / 8 bytes)
-// fits the budget, and nothing asks for the cell-by-cell kernels (matrix dump, forced rows per lane, forced
-// checkpointing, column stripes).  *used = false: the caller takes fill_impl instead.  Events as in fill_impl.
+// per cell.  Applies when the pair holds at most 255 distinct bytes (DNA, proteins, text), the record (m n / 8 bytes)
+// fits the budget or can be recomputed in bands from kept carry records, and nothing asks for the cell-by-cell kernels
+// (matrix dump, forced rows per lane).  *used = false: the caller takes fill_impl instead.  Events as in fill_impl.
 int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n, uint32_t flags, sa_result* out, bool* used,
                   const StripeDesc* sd = nullptr) {
   *used = false;
@@ -839,7 +839,9 @@ int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n,
   // (so does a plain fill: 6.9 TB/s over 256 CUs), and 489 strips as 123 workgroups of four waves use 123 CUs: 2.7 TB/s,
   // 47 ms at 1 Mb x 1 Mb; as 245 workgroups of two waves they use 245.
   const int cap = persist_wg_cap(ctx);
-  const int wpb = ctx->bits_wpb ? ctx->bits_wpb : (S <= 2 * cap ? 2 : kWavesPerBlock);  // (single-wave workgroups are not guaranteed a SIMD of their own)
+  // A wave's profile is 256 B of LDS per symbol (DNA: 1.3 KB; every byte value but one: 64 KB), a workgroup's waves share the CU's 160 KB.
+  const int wpb_fit = std::max(1, std::min(kWavesPerBlock, (int)(kBitsLdsBytes / ((size_t)alpha * 256))));
+  const int wpb = std::min(wpb_fit == 3 ? 2 : wpb_fit, ctx->bits_wpb ? ctx->bits_wpb : (S <= 2 * cap ? 2 : kWavesPerBlock));  // (single-wave workgroups are not guaranteed a SIMD of their own)
   const int grid_blocks = std::min((S + wpb - 1) / wpb, cap);
   const size_t rows_pad = (size_t)S * kBitsStripRows;
   const size_t strip_rec_bytes = ((size_t)Tend * 64 + kBitsStripPad) * 4;

@@ -79,17 +79,27 @@ def test_bits_score_only_and_fallbacks(engine, oracle):
     o = oracle.lcs(x, y)
     g = engine.lcs(x, y, flags=sa.SA_FLAG_NO_TRACEBACK)
     assert g.rows_per_lane == 32 and g.score == o.score and len(g.ops) == 0
-    # more than 63 distinct bytes, a forced rows-per-lane, a matrix dump: the cell-by-cell kernels, same results
-    syms = rng.permutation(256)[:64].astype(np.uint8)
-    xb, yb = syms[rng.integers(0, 64, 3000)], syms[rng.integers(0, 64, 2500)]
-    xb[:64] = syms  # all 64 present
+    # every byte value present (no code left for the padding symbol), a forced rows-per-lane, a matrix dump: the
+    # cell-by-cell kernels, same results; up to 255 distinct bytes the bit-vector kernel (256 B of LDS per symbol and wave:
+    # beyond 127 symbols a workgroup's LDS passes 64 KB, beyond 160 symbols only two waves fit a workgroup)
+    syms = rng.permutation(256).astype(np.uint8)
+    xb, yb = syms[rng.integers(0, 256, 3000)], syms[rng.integers(0, 256, 2500)]
+    xb[:256] = syms  # all 256 present
     g, ob = engine.lcs(xb, yb), oracle.lcs(xb, yb)
     assert g.rows_per_lane != 32 and g.score == ob.score and np.array_equal(g.ops, ob.ops)
-    syms = syms[:63]
-    xb, yb = syms[rng.integers(0, 63, 3000)], syms[rng.integers(0, 63, 2500)]
-    xb[:63] = syms
-    g, ob = engine.lcs(xb, yb), oracle.lcs(xb, yb)
-    assert g.rows_per_lane == 32 and g.score == ob.score and np.array_equal(g.ops, ob.ops)
+    for nsym in (255, 200, 161, 160, 128, 127, 64, 63):
+        sy = syms[:nsym]
+        xb = sy[rng.integers(0, nsym, 5000)]
+        yb = np.concatenate([xb[300:2100], sy[rng.integers(0, nsym, 700)], xb[2500:4800]])
+        xb[:nsym] = sy
+        for wpb in (0, 4, 1):
+            engine.set_option("lcs_bits_waves_per_block", wpb)
+            g, ob = engine.lcs(xb, yb), oracle.lcs(xb, yb)
+            assert g.rows_per_lane == 32 and g.score == ob.score and np.array_equal(g.ops, ob.ops), (nsym, wpb)
+    engine.set_option("lcs_bits_waves_per_block", 0)
+    # the small alphabet of a low-complexity byte text next to a wide one in the same call sequence (LDS size changes per call)
+    g = check("lcs", engine, oracle, rand_seq(rng, 3000, DNA), rand_seq(rng, 2500, DNA), "dna")
+    assert g.rows_per_lane == 32
     engine.set_tuning(4, 0)
     g = engine.lcs(x, y)
     engine.set_tuning(0, 0)
