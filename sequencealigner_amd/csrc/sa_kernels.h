@@ -1027,160 +1027,6 @@ struct MoveEmitter {
   }
 };
 
-// The scalar walk through one 64-row window (traceback_walk).  State, all wave-uniform: dcur = rows of the window
-// already left behind, o = drift from the window's diagonal (-16..15), k / acc = the emitter's word being filled.
-// dm_lo / dm_hi: lane q holds the 64-row mask "the cell at drift q - 16 is a diagonal move"; Flo / Fhi: lane r
-// holds row r's 32 two-bit codes (drift -16 first).  Per round: the diagonal run from (dcur, o) is the run of ones
-// in mask[o] from bit dcur (s_ff1 of its complement) and costs one addition to k (zero codes); then ONE gap move:
-// its code comes out of the row's scalar copy, goes into acc, and moves dcur / o.  Leaves -- with everything
-// consistent, the caller looks at k, dcur, o and the returned code -- when the window is done (dcur >= 64), an SW
-// stop code (3) turns up, or the path drifted out of the window.  A full word of 32 moves is staged right here (out of
-// line: v_mov_b64 + ds_write_b64 at the LDS byte address `saddr`, which advances by 8): leaving the loop for it cost
-// two exits per window, each ~350 cycles of branches and compiled bookkeeping for a lone wave.  vcc is the 64-bit scratch pair
-// (inline asm cannot name the halves of a 64-bit operand).
-__device__ __forceinline__ uint32_t walk_rounds(const bool tagged, const uint32_t dm_lo, const uint32_t dm_hi, const uint32_t Flo,
-                                                const uint32_t Fhi, int& dcur, int& o, int& k, unsigned long long& acc, uint32_t& saddr) {
-  uint32_t c = 0, t0, t1, L;
-  unsigned long long wtmp;
-  if (tagged) {
-    asm volatile(
-        "s_add_i32 %[t0], %[o], 16\n\t"
-        "Ltop_%=:\n\t"                      // t0 = o + 16 here, from above or from the bottom of the round
-        "v_readlane_b32 vcc_hi, %[dmhi], %[t0]\n\t"
-        "v_readlane_b32 vcc_lo, %[dmlo], %[t0]\n\t"
-        "s_lshr_b64 vcc, vcc, %[d]\n\t"
-        "s_not_b64 vcc, vcc\n\t"
-        "s_ff1_i32_b64 %[L], vcc\n\t"
-        "s_sub_i32 %[t1], 64, %[d]\n\t"     // d = 64 can arrive here (an up move out of the last row): the shift was by 0 then
-        "s_min_u32 %[L], %[L], %[t1]\n\t"
-        "s_add_i32 %[k], %[k], %[L]\n\t"
-        "s_add_i32 %[d], %[d], %[L]\n\t"
-        "s_cmp_ge_i32 %[k], 32\n\t"
-        "s_cbranch_scc1 Lword_%=\n\t"
-        "Lback_%=:\n\t"
-        "s_cmp_ge_i32 %[d], 64\n\t"
-        "s_cbranch_scc1 Lout_%=\n\t"
-        "v_readlane_b32 vcc_hi, %[fhi], %[d]\n\t"
-        "v_readlane_b32 vcc_lo, %[flo], %[d]\n\t"
-        "s_lshl_b32 %[t0], %[t0], 1\n\t"
-        "s_lshr_b64 vcc, vcc, %[t0]\n\t"
-        "s_and_b32 %[c], vcc_lo, 3\n\t"
-        "s_cmp_eq_u32 %[c], 3\n\t"
-        "s_cbranch_scc1 Lout_%=\n\t"
-        "s_sub_i32 %[t1], 1, %[c]\n\t"          // 1 for an up move (op 2, tag F = 0), 0 for a left move (op 1, tag E = 1)
-        "s_lshl1_add_u32 %[t0], %[k], %[t1]\n\t"
-        "s_bitset1_b64 %[acc], %[t0]\n\t"       // the op is one set bit of the move's two: 2k (left) or 2k + 1 (up)
-        "s_add_i32 %[k], %[k], 1\n\t"
-        "s_add_i32 %[d], %[d], %[t1]\n\t"
-        "s_lshl1_add_u32 %[o], %[t1], %[o]\n\t"
-        "s_add_i32 %[o], %[o], -1\n\t"
-        "s_add_i32 %[t0], %[o], 16\n\t"
-        "s_cmp_lt_u32 %[t0], 32\n\t"
-        "s_cbranch_scc1 Ltop_%=\n\t"
-        "s_branch Lout_%=\n\t"
-        "Lword_%=:\n\t"                       // a word of 32 moves is full: stage it, start the next
-        "v_mov_b64 %[wtmp], %[acc]\n\t"
-        "ds_write_b64 %[saddr], %[wtmp]\n\t"
-        "v_add_u32 %[saddr], 8, %[saddr]\n\t"
-        "s_mov_b64 %[acc], 0\n\t"
-        "s_sub_i32 %[k], %[k], 32\n\t"
-        "s_cmp_ge_i32 %[k], 32\n\t"
-        "s_cbranch_scc1 Lword_%=\n\t"
-        "s_branch Lback_%=\n\t"
-        "Lout_%=:\n\t"
-        : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [c] "+s"(c), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L),
-          [saddr] "+v"(saddr), [wtmp] "=&v"(wtmp)
-        : [dmlo] "v"(dm_lo), [dmhi] "v"(dm_hi), [flo] "v"(Flo), [fhi] "v"(Fhi)
-        : "scc", "vcc", "memory");
-  } else {  // LCS: codes 3 diagonal, 2 up, 1 left are the ops themselves; there is no stop code
-    asm volatile(
-        "s_add_i32 %[t0], %[o], 16\n\t"
-        "Ltop_%=:\n\t"                      // t0 = o + 16 here, from above or from the bottom of the round
-        "v_readlane_b32 vcc_hi, %[dmhi], %[t0]\n\t"
-        "v_readlane_b32 vcc_lo, %[dmlo], %[t0]\n\t"
-        "s_lshr_b64 vcc, vcc, %[d]\n\t"
-        "s_not_b64 vcc, vcc\n\t"
-        "s_ff1_i32_b64 %[L], vcc\n\t"
-        "s_sub_i32 %[t1], 64, %[d]\n\t"     // d = 64 can arrive here (an up move out of the last row): the shift was by 0 then
-        "s_min_u32 %[L], %[L], %[t1]\n\t"
-        "s_add_i32 %[k], %[k], %[L]\n\t"
-        "s_add_i32 %[d], %[d], %[L]\n\t"
-        "s_cmp_ge_i32 %[k], 32\n\t"
-        "s_cbranch_scc1 Lword_%=\n\t"
-        "Lback_%=:\n\t"
-        "s_cmp_ge_i32 %[d], 64\n\t"
-        "s_cbranch_scc1 Lout_%=\n\t"
-        "v_readlane_b32 vcc_hi, %[fhi], %[d]\n\t"
-        "v_readlane_b32 vcc_lo, %[flo], %[d]\n\t"
-        "s_lshl_b32 %[t0], %[t0], 1\n\t"
-        "s_lshr_b64 vcc, vcc, %[t0]\n\t"
-        "s_bfe_u32 %[t1], vcc_lo, 0x10001\n\t"   // bit 1 of the code (1 left, 2 up): 1 for an up move
-        "s_lshl1_add_u32 %[t0], %[k], %[t1]\n\t"
-        "s_bitset1_b64 %[acc], %[t0]\n\t"
-        "s_add_i32 %[k], %[k], 1\n\t"
-        "s_add_i32 %[d], %[d], %[t1]\n\t"
-        "s_lshl1_add_u32 %[o], %[t1], %[o]\n\t"
-        "s_add_i32 %[o], %[o], -1\n\t"
-        "s_add_i32 %[t0], %[o], 16\n\t"
-        "s_cmp_lt_u32 %[t0], 32\n\t"
-        "s_cbranch_scc1 Ltop_%=\n\t"
-        "s_branch Lout_%=\n\t"
-        "Lword_%=:\n\t"                       // a word of 32 moves is full: stage it, start the next
-        "v_mov_b64 %[wtmp], %[acc]\n\t"
-        "ds_write_b64 %[saddr], %[wtmp]\n\t"
-        "v_add_u32 %[saddr], 8, %[saddr]\n\t"
-        "s_mov_b64 %[acc], 0\n\t"
-        "s_sub_i32 %[k], %[k], 32\n\t"
-        "s_cmp_ge_i32 %[k], 32\n\t"
-        "s_cbranch_scc1 Lword_%=\n\t"
-        "s_branch Lback_%=\n\t"
-        "Lout_%=:\n\t"
-        : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L), [saddr] "+v"(saddr),
-          [wtmp] "=&v"(wtmp)
-        : [dmlo] "v"(dm_lo), [dmhi] "v"(dm_hi), [flo] "v"(Flo), [fhi] "v"(Fhi)
-        : "scc", "vcc", "memory");
-  }
-  return c;
-}
-
-// Lane q of (lo, hi) <- the 64-lane mask "a == b".  One asm statement, because gfx950 wants two wait states between
-// a VALU instruction that writes a scalar register (the compare) and a VALU instruction that reads it as an operand
-// (v_writelane): the compiler inserts them in its own code but does not look inside inline assembly -- as two
-// statements the first v_writelane could see the PREVIOUS compare's mask, depending on what got scheduled between.
-// The same with a = byte B of a dword (SDWA selects it inside the compare: no extraction)
-template <int B>
-__device__ __forceinline__ void ballot_eq_byte_to_lane(uint32_t& lo, uint32_t& hi, uint32_t word, uint32_t b, const int q) {
-  static_assert(B >= 0 && B < 4, "byte of a dword");
-#define SA_BALLOT_BYTE(SEL)                                                  \
-  asm("v_cmp_eq_u32_sdwa vcc, %2, %3 src0_sel:" SEL " src1_sel:DWORD\n\t"     \
-      "s_nop 1\n\t"                                                          \
-      "v_writelane_b32 %0, vcc_lo, %4\n\t"                                   \
-      "v_writelane_b32 %1, vcc_hi, %4"                                        \
-      : "+v"(lo), "+v"(hi)                                                   \
-      : "v"(word), "v"(b), "n"(q)                                            \
-      : "vcc")
-  if constexpr (B == 0) SA_BALLOT_BYTE("BYTE_0");
-  else if constexpr (B == 1) SA_BALLOT_BYTE("BYTE_1");
-  else if constexpr (B == 2) SA_BALLOT_BYTE("BYTE_2");
-  else SA_BALLOT_BYTE("BYTE_3");
-#undef SA_BALLOT_BYTE
-}
-// lane q of (lo, hi) <- "byte q of the lane's 32 bytes yv[0..7] equals b", q = 0..31
-template <int... Q>
-__device__ __forceinline__ void ballot_bytes_to_lanes(uint32_t& lo, uint32_t& hi, const uint32_t (&yv)[8], uint32_t b,
-                                                      std::integer_sequence<int, Q...>) {
-  (ballot_eq_byte_to_lane<(Q & 3)>(lo, hi, yv[Q >> 2], b, Q), ...);
-}
-__device__ __forceinline__ void ballot_eq_to_lane(uint32_t& lo, uint32_t& hi, uint32_t a, uint32_t b, const int q) {
-  asm("v_cmp_eq_u32_e64 vcc, %2, %3\n\t"
-      "s_nop 1\n\t"
-      "v_writelane_b32 %0, vcc_lo, %4\n\t"
-      "v_writelane_b32 %1, vcc_hi, %4"
-      : "+v"(lo), "+v"(hi)
-      : "v"(a), "v"(b), "n"(q)
-      : "vcc");
-}
-
 // ---- bit-vector LCS (sa_lcsbits.hip): the same walker over one bit per cell ----
 // The fill stores, per column, the vertical differences of the L matrix as bit vectors: bit (r & 31) of dword
 // [strip][t / 4][lane][t % 4], t = step c + kBitsSkew * lane (row r 0-based in word g = r >> 5 = strip * 64 + lane, column c 0-based) is CLEAR iff
@@ -1230,19 +1076,309 @@ __device__ __forceinline__ BitsWindow load_bits_window(const TraceArgs& a, int i
   w.xv = a.xs[i - 1 - q];
   return w;
 }
-// walk_rounds for the bit-vector window.  dm as there (lane q: the 64-row mask "drift q - 16 is a match"); ca / cb:
-// lane q holds the 64 row bits (bit d = row i - d) of column j0 - 79 + q / j0 - 15 + q.  The gap move at (d, o) sits in
-// column j0 - d + o = lane 79 - d + o of ca, or of cb when that is 64 or more (v_readlane takes the lane modulo 64).
-__device__ __forceinline__ void walk_rounds_bits(const uint32_t dm_lo, const uint32_t dm_hi, const uint32_t ca_lo, const uint32_t ca_hi,
+// ---- the scalar walk through one 64-row window (traceback_walk) ----
+// State, all wave-uniform: dcur = rows of the window already left behind, o = drift from the window's diagonal
+// (-16..15), k / acc = the emitter's word being filled.  diagmask[q], q = o + 16: the 64-row mask "the cell at drift
+// q - 16 is a diagonal move"; Flo / Fhi: lane r holds row r's 32 two-bit codes (drift -16 first).  Per round: the
+// diagonal run from (dcur, o) is the run of ones in mask[o] from bit dcur (s_ff1 of its complement) and costs one
+// addition to k (zero codes); then ONE gap move: its code comes out of the row's scalar copy, goes into acc, and moves
+// dcur / o.  Leaves -- with everything consistent, the caller looks at k, dcur, o and the returned code -- when the
+// window is done (dcur >= 64), an SW stop code (3) turns up, or the path drifted out of the window.  A full word of 32
+// moves is staged right here (out of line: v_mov_b64 + ds_write_b64 at the LDS byte address `saddr`, which advances by
+// 8): leaving the loop for it cost two exits per window, each ~350 cycles of branches and compiled bookkeeping for a
+// lone wave.  vcc is the 64-bit scratch pair (inline asm cannot name the halves of a 64-bit operand).
+// Round 3: the masks are built by 32 compares that write their 64-bit results straight into s[36:99]
+// (v_cmp_eq_u32_e64 sdst / the SDWA form with a byte select for the bit-vector record) and are fetched in the round loop
+// with s_movrels_b64 (M0 = 2 (o + 16), which is also the shift that brings the row's code at this drift down).  Rounds 1-2
+// parked them in lanes 0..31 of two VGPRs: a compare, two wait states (gfx950 wants them between a VALU write of a
+// scalar register and a v_writelane that reads it; the compiler does not look inside inline assembly) and two
+// v_writelane per drift, two v_readlane per round.  Set-up and loop are ONE asm statement: the masks live in registers
+// the compiler only knows as clobbered.  M0 is not used by anything else in this kernel (gfx9 DS instructions do not
+// read it).  The bit-vector window: ca / cb, lane q holds the 64 row bits (bit d = row i - d) of column j0 - 79 + q /
+// j0 - 15 + q; the gap move at (d, o) sits in column j0 - d + o = lane 79 - d + o of ca, or of cb when that is 64 or
+// more (v_readlane takes the lane modulo 64).
+#define SA_WALK_MASK_CLOBBERS "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
+template <bool TAGGED>
+__device__ __forceinline__ uint32_t walk_window(const uint32_t Flo, const uint32_t Fhi, int& dcur, int& o, int& k, unsigned long long& acc,
+                                                uint32_t& saddr) {
+  uint32_t c = 0, t0, t1, L, vt;
+  unsigned long long wtmp;
+  if constexpr (TAGGED) {  // NW / SW: diagonal = tag M (2); the gap move is 2 - tag (E = 1 left, F = 0 up); tag 3 is SW's stop cell
+    asm volatile(
+        "v_bfe_u32 %[vt], %[flo], 0, 2\n\t"
+        "v_cmp_eq_u32_e64 s[36:37], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 2, 2\n\t"
+        "v_cmp_eq_u32_e64 s[38:39], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 4, 2\n\t"
+        "v_cmp_eq_u32_e64 s[40:41], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 6, 2\n\t"
+        "v_cmp_eq_u32_e64 s[42:43], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 8, 2\n\t"
+        "v_cmp_eq_u32_e64 s[44:45], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 10, 2\n\t"
+        "v_cmp_eq_u32_e64 s[46:47], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 12, 2\n\t"
+        "v_cmp_eq_u32_e64 s[48:49], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 14, 2\n\t"
+        "v_cmp_eq_u32_e64 s[50:51], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 16, 2\n\t"
+        "v_cmp_eq_u32_e64 s[52:53], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 18, 2\n\t"
+        "v_cmp_eq_u32_e64 s[54:55], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 20, 2\n\t"
+        "v_cmp_eq_u32_e64 s[56:57], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 22, 2\n\t"
+        "v_cmp_eq_u32_e64 s[58:59], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 24, 2\n\t"
+        "v_cmp_eq_u32_e64 s[60:61], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 26, 2\n\t"
+        "v_cmp_eq_u32_e64 s[62:63], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 28, 2\n\t"
+        "v_cmp_eq_u32_e64 s[64:65], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 30, 2\n\t"
+        "v_cmp_eq_u32_e64 s[66:67], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 0, 2\n\t"
+        "v_cmp_eq_u32_e64 s[68:69], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 2, 2\n\t"
+        "v_cmp_eq_u32_e64 s[70:71], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 4, 2\n\t"
+        "v_cmp_eq_u32_e64 s[72:73], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 6, 2\n\t"
+        "v_cmp_eq_u32_e64 s[74:75], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 8, 2\n\t"
+        "v_cmp_eq_u32_e64 s[76:77], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 10, 2\n\t"
+        "v_cmp_eq_u32_e64 s[78:79], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 12, 2\n\t"
+        "v_cmp_eq_u32_e64 s[80:81], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 14, 2\n\t"
+        "v_cmp_eq_u32_e64 s[82:83], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 16, 2\n\t"
+        "v_cmp_eq_u32_e64 s[84:85], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 18, 2\n\t"
+        "v_cmp_eq_u32_e64 s[86:87], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 20, 2\n\t"
+        "v_cmp_eq_u32_e64 s[88:89], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 22, 2\n\t"
+        "v_cmp_eq_u32_e64 s[90:91], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 24, 2\n\t"
+        "v_cmp_eq_u32_e64 s[92:93], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 26, 2\n\t"
+        "v_cmp_eq_u32_e64 s[94:95], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 28, 2\n\t"
+        "v_cmp_eq_u32_e64 s[96:97], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 30, 2\n\t"
+        "v_cmp_eq_u32_e64 s[98:99], %[vt], 2\n\t"
+        "s_nop 3\n\t"
+        "s_add_i32 %[t0], %[o], 16\n\t"
+        "Ltop_%=:\n\t"                      // t0 = o + 16 here, from above or from the bottom of the round
+        "s_lshl_b32 m0, %[t0], 1\n\t"
+        "s_nop 0\n\t"
+        "s_movrels_b64 vcc, s[36:37]\n\t"
+        "s_lshr_b64 vcc, vcc, %[d]\n\t"
+        "s_not_b64 vcc, vcc\n\t"
+        "s_ff1_i32_b64 %[L], vcc\n\t"
+        "s_sub_i32 %[t1], 64, %[d]\n\t"     // d = 64 can arrive here (an up move out of the last row): the shift was by 0 then
+        "s_min_u32 %[L], %[L], %[t1]\n\t"
+        "s_add_i32 %[k], %[k], %[L]\n\t"
+        "s_add_i32 %[d], %[d], %[L]\n\t"
+        "s_cmp_ge_i32 %[k], 32\n\t"
+        "s_cbranch_scc1 Lword_%=\n\t"
+        "Lback_%=:\n\t"
+        "s_cmp_ge_i32 %[d], 64\n\t"
+        "s_cbranch_scc1 Lout_%=\n\t"
+        "v_readlane_b32 vcc_hi, %[fhi], %[d]\n\t"
+        "v_readlane_b32 vcc_lo, %[flo], %[d]\n\t"
+        "s_lshr_b64 vcc, vcc, m0\n\t"         // M0 is still 2 (o + 16): the row's code at this drift
+        "s_and_b32 %[c], vcc_lo, 3\n\t"
+        "s_cmp_eq_u32 %[c], 3\n\t"
+        "s_cbranch_scc1 Lout_%=\n\t"
+        "s_sub_i32 %[t1], 1, %[c]\n\t"          // 1 for an up move (op 2, tag F = 0), 0 for a left move (op 1, tag E = 1)
+        "s_lshl1_add_u32 %[t0], %[k], %[t1]\n\t"
+        "s_bitset1_b64 %[acc], %[t0]\n\t"       // the op is one set bit of the move's two: 2k (left) or 2k + 1 (up)
+        "s_add_i32 %[k], %[k], 1\n\t"
+        "s_add_i32 %[d], %[d], %[t1]\n\t"
+        "s_lshl1_add_u32 %[o], %[t1], %[o]\n\t"
+        "s_add_i32 %[o], %[o], -1\n\t"
+        "s_add_i32 %[t0], %[o], 16\n\t"
+        "s_cmp_lt_u32 %[t0], 32\n\t"
+        "s_cbranch_scc1 Ltop_%=\n\t"
+        "s_branch Lout_%=\n\t"
+        "Lword_%=:\n\t"                       // a word of 32 moves is full: stage it, start the next
+        "v_mov_b64 %[wtmp], %[acc]\n\t"
+        "ds_write_b64 %[saddr], %[wtmp]\n\t"
+        "v_add_u32 %[saddr], 8, %[saddr]\n\t"
+        "s_mov_b64 %[acc], 0\n\t"
+        "s_sub_i32 %[k], %[k], 32\n\t"
+        "s_cmp_ge_i32 %[k], 32\n\t"
+        "s_cbranch_scc1 Lword_%=\n\t"
+        "s_branch Lback_%=\n\t"
+        "Lout_%=:\n\t"
+        : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [c] "+s"(c), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L),
+          [saddr] "+v"(saddr), [wtmp] "=&v"(wtmp), [vt] "=&v"(vt)
+        : [flo] "v"(Flo), [fhi] "v"(Fhi)
+        : "scc", "vcc", "memory", SA_WALK_MASK_CLOBBERS);
+  } else {  // LCS cell kernels: codes 3 diagonal, 2 up, 1 left are the ops themselves; there is no stop code
+    asm volatile(
+        "v_bfe_u32 %[vt], %[flo], 0, 2\n\t"
+        "v_cmp_eq_u32_e64 s[36:37], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[flo], 2, 2\n\t"
+        "v_cmp_eq_u32_e64 s[38:39], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[flo], 4, 2\n\t"
+        "v_cmp_eq_u32_e64 s[40:41], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[flo], 6, 2\n\t"
+        "v_cmp_eq_u32_e64 s[42:43], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[flo], 8, 2\n\t"
+        "v_cmp_eq_u32_e64 s[44:45], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[flo], 10, 2\n\t"
+        "v_cmp_eq_u32_e64 s[46:47], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[flo], 12, 2\n\t"
+        "v_cmp_eq_u32_e64 s[48:49], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[flo], 14, 2\n\t"
+        "v_cmp_eq_u32_e64 s[50:51], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[flo], 16, 2\n\t"
+        "v_cmp_eq_u32_e64 s[52:53], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[flo], 18, 2\n\t"
+        "v_cmp_eq_u32_e64 s[54:55], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[flo], 20, 2\n\t"
+        "v_cmp_eq_u32_e64 s[56:57], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[flo], 22, 2\n\t"
+        "v_cmp_eq_u32_e64 s[58:59], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[flo], 24, 2\n\t"
+        "v_cmp_eq_u32_e64 s[60:61], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[flo], 26, 2\n\t"
+        "v_cmp_eq_u32_e64 s[62:63], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[flo], 28, 2\n\t"
+        "v_cmp_eq_u32_e64 s[64:65], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[flo], 30, 2\n\t"
+        "v_cmp_eq_u32_e64 s[66:67], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 0, 2\n\t"
+        "v_cmp_eq_u32_e64 s[68:69], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 2, 2\n\t"
+        "v_cmp_eq_u32_e64 s[70:71], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 4, 2\n\t"
+        "v_cmp_eq_u32_e64 s[72:73], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 6, 2\n\t"
+        "v_cmp_eq_u32_e64 s[74:75], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 8, 2\n\t"
+        "v_cmp_eq_u32_e64 s[76:77], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 10, 2\n\t"
+        "v_cmp_eq_u32_e64 s[78:79], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 12, 2\n\t"
+        "v_cmp_eq_u32_e64 s[80:81], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 14, 2\n\t"
+        "v_cmp_eq_u32_e64 s[82:83], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 16, 2\n\t"
+        "v_cmp_eq_u32_e64 s[84:85], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 18, 2\n\t"
+        "v_cmp_eq_u32_e64 s[86:87], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 20, 2\n\t"
+        "v_cmp_eq_u32_e64 s[88:89], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 22, 2\n\t"
+        "v_cmp_eq_u32_e64 s[90:91], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 24, 2\n\t"
+        "v_cmp_eq_u32_e64 s[92:93], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 26, 2\n\t"
+        "v_cmp_eq_u32_e64 s[94:95], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 28, 2\n\t"
+        "v_cmp_eq_u32_e64 s[96:97], %[vt], 3\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 30, 2\n\t"
+        "v_cmp_eq_u32_e64 s[98:99], %[vt], 3\n\t"
+        "s_nop 3\n\t"
+        "s_add_i32 %[t0], %[o], 16\n\t"
+        "Ltop_%=:\n\t"                      // t0 = o + 16 here, from above or from the bottom of the round
+        "s_lshl_b32 m0, %[t0], 1\n\t"
+        "s_nop 0\n\t"
+        "s_movrels_b64 vcc, s[36:37]\n\t"
+        "s_lshr_b64 vcc, vcc, %[d]\n\t"
+        "s_not_b64 vcc, vcc\n\t"
+        "s_ff1_i32_b64 %[L], vcc\n\t"
+        "s_sub_i32 %[t1], 64, %[d]\n\t"     // d = 64 can arrive here (an up move out of the last row): the shift was by 0 then
+        "s_min_u32 %[L], %[L], %[t1]\n\t"
+        "s_add_i32 %[k], %[k], %[L]\n\t"
+        "s_add_i32 %[d], %[d], %[L]\n\t"
+        "s_cmp_ge_i32 %[k], 32\n\t"
+        "s_cbranch_scc1 Lword_%=\n\t"
+        "Lback_%=:\n\t"
+        "s_cmp_ge_i32 %[d], 64\n\t"
+        "s_cbranch_scc1 Lout_%=\n\t"
+        "v_readlane_b32 vcc_hi, %[fhi], %[d]\n\t"
+        "v_readlane_b32 vcc_lo, %[flo], %[d]\n\t"
+        "s_lshr_b64 vcc, vcc, m0\n\t"         // M0 is still 2 (o + 16): the row's code at this drift
+        "s_bfe_u32 %[t1], vcc_lo, 0x10001\n\t"   // bit 1 of the code (1 left, 2 up): 1 for an up move
+        "s_lshl1_add_u32 %[t0], %[k], %[t1]\n\t"
+        "s_bitset1_b64 %[acc], %[t0]\n\t"       // the op is one set bit of the move's two: 2k (left) or 2k + 1 (up)
+        "s_add_i32 %[k], %[k], 1\n\t"
+        "s_add_i32 %[d], %[d], %[t1]\n\t"
+        "s_lshl1_add_u32 %[o], %[t1], %[o]\n\t"
+        "s_add_i32 %[o], %[o], -1\n\t"
+        "s_add_i32 %[t0], %[o], 16\n\t"
+        "s_cmp_lt_u32 %[t0], 32\n\t"
+        "s_cbranch_scc1 Ltop_%=\n\t"
+        "s_branch Lout_%=\n\t"
+        "Lword_%=:\n\t"                       // a word of 32 moves is full: stage it, start the next
+        "v_mov_b64 %[wtmp], %[acc]\n\t"
+        "ds_write_b64 %[saddr], %[wtmp]\n\t"
+        "v_add_u32 %[saddr], 8, %[saddr]\n\t"
+        "s_mov_b64 %[acc], 0\n\t"
+        "s_sub_i32 %[k], %[k], 32\n\t"
+        "s_cmp_ge_i32 %[k], 32\n\t"
+        "s_cbranch_scc1 Lword_%=\n\t"
+        "s_branch Lback_%=\n\t"
+        "Lout_%=:\n\t"
+        : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [c] "+s"(c), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L),
+          [saddr] "+v"(saddr), [wtmp] "=&v"(wtmp), [vt] "=&v"(vt)
+        : [flo] "v"(Flo), [fhi] "v"(Fhi)
+        : "scc", "vcc", "memory", SA_WALK_MASK_CLOBBERS);
+  }
+  return c;
+}
+
+// the same for the bit-vector record: masks from the symbols (yv: the lane's 32 target symbols as bytes, xv: the symbol of its row)
+__device__ __forceinline__ void walk_window_bits(const uint32_t (&yv)[8], const uint32_t xv, const uint32_t ca_lo, const uint32_t ca_hi,
                                                  const uint32_t cb_lo, const uint32_t cb_hi, int& dcur, int& o, int& k,
                                                  unsigned long long& acc, uint32_t& saddr) {
   uint32_t t0, t1, L;
   unsigned long long wtmp;
   asm volatile(
+      "v_cmp_eq_u32_sdwa s[36:37], %[y0], %[xv] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[38:39], %[y0], %[xv] src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[40:41], %[y0], %[xv] src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[42:43], %[y0], %[xv] src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[44:45], %[y1], %[xv] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[46:47], %[y1], %[xv] src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[48:49], %[y1], %[xv] src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[50:51], %[y1], %[xv] src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[52:53], %[y2], %[xv] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[54:55], %[y2], %[xv] src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[56:57], %[y2], %[xv] src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[58:59], %[y2], %[xv] src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[60:61], %[y3], %[xv] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[62:63], %[y3], %[xv] src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[64:65], %[y3], %[xv] src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[66:67], %[y3], %[xv] src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[68:69], %[y4], %[xv] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[70:71], %[y4], %[xv] src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[72:73], %[y4], %[xv] src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[74:75], %[y4], %[xv] src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[76:77], %[y5], %[xv] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[78:79], %[y5], %[xv] src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[80:81], %[y5], %[xv] src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[82:83], %[y5], %[xv] src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[84:85], %[y6], %[xv] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[86:87], %[y6], %[xv] src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[88:89], %[y6], %[xv] src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[90:91], %[y6], %[xv] src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[92:93], %[y7], %[xv] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[94:95], %[y7], %[xv] src0_sel:BYTE_1 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[96:97], %[y7], %[xv] src0_sel:BYTE_2 src1_sel:DWORD\n\t"
+      "v_cmp_eq_u32_sdwa s[98:99], %[y7], %[xv] src0_sel:BYTE_3 src1_sel:DWORD\n\t"
+      "s_nop 3\n\t"
       "s_add_i32 %[t0], %[o], 16\n\t"
       "Ltop_%=:\n\t"
-      "v_readlane_b32 vcc_hi, %[dmhi], %[t0]\n\t"
-      "v_readlane_b32 vcc_lo, %[dmlo], %[t0]\n\t"
+      "s_lshl_b32 m0, %[t0], 1\n\t"
+      "s_nop 0\n\t"
+      "s_movrels_b64 vcc, s[36:37]\n\t"
       "s_lshr_b64 vcc, vcc, %[d]\n\t"
       "s_not_b64 vcc, vcc\n\t"
       "s_ff1_i32_b64 %[L], vcc\n\t"
@@ -1276,7 +1412,7 @@ __device__ __forceinline__ void walk_rounds_bits(const uint32_t dm_lo, const uin
       "s_cmp_lt_u32 %[t0], 32\n\t"
       "s_cbranch_scc1 Ltop_%=\n\t"
       "s_branch Lout_%=\n\t"
-      "Lword_%=:\n\t"                       // a word of 32 moves is full: stage it, start the next
+      "Lword_%=:\n\t"
       "v_mov_b64 %[wtmp], %[acc]\n\t"
       "ds_write_b64 %[saddr], %[wtmp]\n\t"
       "v_add_u32 %[saddr], 8, %[saddr]\n\t"
@@ -1288,13 +1424,17 @@ __device__ __forceinline__ void walk_rounds_bits(const uint32_t dm_lo, const uin
       "Lout_%=:\n\t"
       : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L), [saddr] "+v"(saddr),
         [wtmp] "=&v"(wtmp)
-      : [dmlo] "v"(dm_lo), [dmhi] "v"(dm_hi), [calo] "v"(ca_lo), [cahi] "v"(ca_hi), [cblo] "v"(cb_lo), [cbhi] "v"(cb_hi)
-      : "scc", "vcc", "memory");
+      : [y0] "v"(yv[0]), [y1] "v"(yv[1]), [y2] "v"(yv[2]), [y3] "v"(yv[3]), [y4] "v"(yv[4]), [y5] "v"(yv[5]), [y6] "v"(yv[6]), [y7] "v"(yv[7]),
+        [xv] "v"(xv), [calo] "v"(ca_lo), [cahi] "v"(ca_hi), [cblo] "v"(cb_lo), [cbhi] "v"(cb_hi)
+      : "scc", "vcc", "memory", SA_WALK_MASK_CLOBBERS);
 }
 
-// BITS: the bit-vector LCS format above instead of 2-bit codes (bands: the record starts with row i_min's strip)
-template <bool BITS>
+// BITS: the bit-vector LCS format above instead of 2-bit codes (bands: the record starts with row i_min's strip).
+// TAGGED: NW / SW codes (the winner's tag) as opposed to the LCS cell kernels' pointers; a template parameter, because the
+// two window loops as branches of one function leave the register allocator with SGPR values it cannot place.
+template <bool BITS, bool TAGGED = false>
 __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
+  static_assert(!(BITS && TAGGED), "the bit-vector record is LCS only");
   // The packed moves are staged in LDS and written out in bulk: with no global stores inside the walk, the
   // only vector-memory operations in flight are the loads of the NEXT window, so waiting for them
   // at the top of the next round (vmcnt counts loads and stores together, in order) waits for
@@ -1302,7 +1442,7 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
   __shared__ unsigned long long stage[kTraceStageWords];
   __shared__ __attribute__((aligned(16))) uint8_t ywin[BITS ? 128 : 16];  // BITS: the target symbols of the window's 96 columns
   const int d = threadIdx.x;
-  const bool tagged = a.kind != KIND_LCS;
+  constexpr bool tagged = TAGGED;
   int lgK = 0;
   while ((1 << lgK) < a.K) ++lgK;
   int i = a.m, j = a.n;
@@ -1339,7 +1479,6 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
   }
   const int i_min = a.i_min;
   // raw codes: NW / SW store the winner's tag (M 2, E 1, F 0, SW zero cell 3), LCS diagonal 3, up 2, left 1
-  const uint32_t rawD = tagged ? 2u : 3u;
   bool have = false;  // nw holds the window of entry cell (pi, pj)
   int pi = 0, pj = 0;
   using Window = std::conditional_t<BITS, BitsWindow, TraceWindow>;
@@ -1374,8 +1513,8 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
         nw = load_window(pi, pj);
       }
       const int o_in = o;
-      uint32_t dm_lo = 0, dm_hi = 0;
       uint32_t Flo = 0, Fhi = 0, ca_lo = 0, ca_hi = 0, cb_lo = 0, cb_hi = 0;
+      uint32_t yvs[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // BITS: the lane's 32 target symbols
       if constexpr (BITS) {
         // rows i-64 .. i-1 (0-based) start at bit sh of the three dwords; reversed, so that bit d is row i - d
         const int sh = (i - 64) & 31;
@@ -1398,27 +1537,22 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
         for (int k = 0; k < 9; ++k) yr[k] = yw32[yw0 + k];
 #pragma unroll
         for (int k = 0; k < 8; ++k) yv[k] = __builtin_amdgcn_alignbyte(yr[k + 1], yr[k], ysh);
-        ballot_bytes_to_lanes(dm_lo, dm_hi, yv, w.xv, std::make_integer_sequence<int, 32>{});
+        for (int k = 0; k < 8; ++k) yvs[k] = yv[k];
       } else {
       // The lane's 32 codes around its own cell of the entry diagonal, as one 64-bit value: the code
       // at drift o (-16..15) is bits [2(o+16), 2(o+16)+1] (two funnel shifts per window).
       const int sh0 = 2 * (w.pb - 16);
       Flo = __builtin_amdgcn_alignbit(w.w1, w.w0, sh0), Fhi = __builtin_amdgcn_alignbit(w.w2, w.w1, sh0);
-      // Walk the window on the scalar unit.  diagmask[q] (lane q of dm_lo / dm_hi, q = drift + 16) says for which of
-      // the 64 rows the cell at that drift is a diagonal move: one ballot per drift, 32 per window, all lanes at
-      // once.  Then every round of the loop below is "the diagonal run from here (a shift and a find-first-zero on
-      // that mask, possibly empty), then ONE gap move (the row's codes sit in two scalar registers: a shift, an
-      // OR into the emitter)" -- no vector work and no memory access per move, one round per gap move.
-#pragma unroll
-      for (int q = 0; q < 32; ++q) {
-        const uint32_t cq = ((q < 16 ? Flo : Fhi) >> (2 * (q & 15))) & 3u;
-        ballot_eq_to_lane(dm_lo, dm_hi, cq, rawD, q);
-      }
+      // Walk the window on the scalar unit.  diagmask[q] (an SGPR pair, q = drift + 16) says for which of the 64 rows the
+      // cell at that drift is a diagonal move: one compare per drift, 32 per window, all lanes at once (walk_window).
+      // Then every round of the loop is "the diagonal run from here (a shift and a find-first-zero on that mask,
+      // possibly empty), then ONE gap move (the row's codes sit in two scalar registers: a shift, an OR into the
+      // emitter)" -- no vector work and no memory access per move, one round per gap move.
       }
 #ifdef SA_DEBUG_BITS
       if constexpr (BITS) {
-        printf("W i=%d j0=%d o=%d lane=%d xv=%u ya=%u yb=%u a=%08x %08x %08x b=%08x %08x %08x dm=%08x%08x ca=%08x%08x cb=%08x%08x\n", i, j0, o, d, w.xv, w.ya,
-               w.yb, w.a0, w.a1, w.a2, w.b0, w.b1, w.b2, dm_hi, dm_lo, ca_hi, ca_lo, cb_hi, cb_lo);
+        printf("W i=%d j0=%d o=%d lane=%d xv=%u ya=%u yb=%u a=%08x %08x %08x b=%08x %08x %08x ca=%08x%08x cb=%08x%08x\n", i, j0, o, d, w.xv, w.ya,
+               w.yb, w.a0, w.a1, w.a2, w.b0, w.b1, w.b2, ca_hi, ca_lo, cb_hi, cb_lo);
       }
 #endif
       int dcur = 0;
@@ -1433,9 +1567,9 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
         // took four taken branches per round, and a lone wave pays ~50 cycles of instruction fetch for each.
         uint32_t c = 0;
         if constexpr (BITS)
-          walk_rounds_bits(dm_lo, dm_hi, ca_lo, ca_hi, cb_lo, cb_hi, dcur, o, k, acc, saddr);
+          walk_window_bits(yvs, w.xv, ca_lo, ca_hi, cb_lo, cb_hi, dcur, o, k, acc, saddr);
         else
-          c = walk_rounds(tagged, dm_lo, dm_hi, Flo, Fhi, dcur, o, k, acc, saddr);
+          c = walk_window<TAGGED>(Flo, Fhi, dcur, o, k, acc, saddr);
         while (k >= 32) {  // the loop was left right after the move that filled a word
           stage[((uint32_t)__builtin_amdgcn_readfirstlane((int)saddr) - stage0) >> 3] = acc;  // all lanes, same word, same place
           saddr += 8;

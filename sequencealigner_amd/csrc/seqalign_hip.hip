@@ -984,6 +984,14 @@ int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n,
   return SA_OK;
 }
 
+// the walker over 2-bit codes: NW / SW tags or the LCS cell kernels' pointers
+static void launch_traceback_walk(hipStream_t st, const TraceArgs& t) {
+  if (t.kind != KIND_LCS)
+    hipLaunchKernelGGL((traceback_walk<false, true>), dim3(1), dim3(64), 0, st, t);
+  else
+    hipLaunchKernelGGL((traceback_walk<false, false>), dim3(1), dim3(64), 0, st, t);
+}
+
 // Traceback after a checkpointed fill: from the start cell upwards, recompute the codes of `band`
 // strips at a time (the persistent kernel restricted to those strips, reading the kept bottom row
 // of the strip above the band) and let the walker cross the band; it hands (i, j) over at the
@@ -1055,7 +1063,7 @@ int traceback_ckpt(sa_ctx* ctx, int start_i, int start_j, sa_result* out) {
       t.ys = (const uint8_t*)ctx->yenc.p;
       bits_launch_traceback(st, t);
     } else {
-      hipLaunchKernelGGL(traceback_walk<false>, dim3(1), dim3(64), 0, st, t);
+      launch_traceback_walk(st, t);
     }
     HIPCK(ctx, hipGetLastError());
     long long h_hdr[5] = {0, 0, 0, 0, 0};
@@ -1123,7 +1131,7 @@ int traceback_impl(sa_ctx* ctx, int start_i, int start_j, bool want_tb, sa_resul
       t.ys = (const uint8_t*)ctx->yenc.p;
       bits_launch_traceback(st, t);
     } else {
-      hipLaunchKernelGGL(traceback_walk<false>, dim3(1), dim3(64), 0, st, t);
+      launch_traceback_walk(st, t);
     }
     launch_expand_ops(ctx, m, n, (long long)m + n, d_hdr);
     HIPCK(ctx, hipGetLastError());

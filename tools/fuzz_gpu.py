@@ -49,6 +49,13 @@ while time.time() - t0 < budget:
     eng.set_option("group", group)  # fill_group instead of fill_persistent (NW / SW, persistent schedule)
     eng.set_option("max_workgroups", int(rng.choice([0, 0, 0, 1, 2, 7])))
     if kind == "lcs":
+        if rng.random() < 0.15:  # byte text over a wide alphabet (up to 255 symbols: the bit-vector kernel; all 256: the cell kernels)
+            nsym = int(rng.choice([64, 65, 127, 128, 129, 160, 161, 200, 255, 256]))
+            syms = rng.permutation(256)[:nsym].astype(np.uint8)
+            x = syms[rng.integers(0, nsym, len(x))]
+            y = np.concatenate([x[len(x) // 5:], syms[rng.integers(0, nsym, int(rng.integers(1, 400)))], x[:len(x) // 7]])
+            if rng.random() < 0.5 and len(x) >= nsym:
+                x[:nsym] = syms
         g, o = eng.lcs(x, y, flags=flags), orc.lcs(x, y)
     else:
         g, o = getattr(eng, kind)(x, y, mode, go, ge, flags=flags), getattr(orc, kind)(x, y, mode, go, ge)
