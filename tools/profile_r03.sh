@@ -18,7 +18,7 @@ run() {  # name, seconds, rocprof args..., -- program
   return $rc
 }
 B="python3 $ROOT/bench.py --no-cpu --no-small"
-PART=${1:-all}   # a | b | all: gpurun limits one call to 20 minutes
+PART=${1:-all}   # a | b | all | s (kernel-trace stats only): gpurun limits one call to 20 minutes
 SQ="SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU SQ_WAVES"
 if [ "$PART" != b ]; then
 run stats_1m   240 --kernel-trace --stats --output-format csv -d "$OUT/stats_1m"   -- $B --steps 3 --warmup 1 --no-batch || exit 1
@@ -27,9 +27,12 @@ run stats_100k_unrel 120 --kernel-trace --stats --output-format csv -d "$OUT/sta
 run stats_lcs1m 240 --kernel-trace --stats --output-format csv -d "$OUT/stats_lcs1m" -- $B --steps 3 --warmup 1 --no-batch --kind lcs || exit 1
 run stats_sw1m 240 --kernel-trace --stats --output-format csv -d "$OUT/stats_sw1m" -- $B --steps 3 --warmup 1 --no-batch --kind sw || exit 1
 run stats_2m 300 --kernel-trace --stats --output-format csv -d "$OUT/stats_2m" -- $B --steps 1 --warmup 0 --no-batch --size 2000000 || exit 1
+run stats_lcs2m 300 --kernel-trace --stats --output-format csv -d "$OUT/stats_lcs2m" -- $B --steps 1 --warmup 0 --no-batch --size 2000000 --kind lcs || exit 1
+run stats_1m_unrel 240 --kernel-trace --stats --output-format csv -d "$OUT/stats_1m_unrel" -- $B --steps 3 --warmup 1 --no-batch --unrelated || exit 1
 run stats_batch 240 --kernel-trace --stats --output-format csv -d "$OUT/stats_batch" -- $B --steps 2 --warmup 1 --workload batch || exit 1
 WL="1m 100k lcs1m"
 fi
+if [ "$PART" = s ]; then WL=""; fi
 if [ "$PART" = b ]; then WL="sw1m batch"; fi
 if [ "$PART" = all ]; then WL="1m 100k lcs1m sw1m batch"; fi
 for w in $WL; do
@@ -44,7 +47,7 @@ for w in $WL; do
   run pmc_fetch_$w 240 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch_$w" -- $B $ARGS || exit 1
   run pmc_sq_$w    240 --pmc $SQ GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_sq_$w" -- $B $ARGS || exit 1
 done
-if [ "$PART" != a ]; then
+if [ "$PART" != a ] && [ "$PART" != s ]; then
 # the second wave per SIMD: fill_group with one and with two workgroups per CU (the library reads
 # SA_GROUP / SA_WPS when the context is created; exported here, in front of rocprofv3, not inside its command)
 for wps in 1 2; do
