@@ -1101,12 +1101,13 @@ __device__ __forceinline__ BitsWindow load_bits_window(const TraceArgs& a, int i
 // j0 - 15 + q; the gap move at (d, o) sits in column j0 - d + o = lane 79 - d + o of ca, or of cb when that is 64 or
 // more (v_readlane takes the lane modulo 64).
 #define SA_WALK_MASK_CLOBBERS "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45", "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69", "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97", "s98", "s99"
-template <bool TAGGED>
+// CODES: 0 the LCS cell kernels' pointers (3 diagonal, 2 up, 1 left), 1 NW tags (M 2, E 1, F 0), 2 SW tags (+ 3: stop cell)
+template <int CODES>
 __device__ __forceinline__ uint32_t walk_window(const uint32_t Flo, const uint32_t Fhi, int& dcur, int& o, int& k, unsigned long long& acc,
                                                 uint32_t& saddr) {
   uint32_t c = 0, t0, t1, L, vt;
   unsigned long long wtmp;
-  if constexpr (TAGGED) {  // NW / SW: diagonal = tag M (2); the gap move is 2 - tag (E = 1 left, F = 0 up); tag 3 is SW's stop cell
+  if constexpr (CODES == 1) {
     asm volatile(
         "v_bfe_u32 %[vt], %[flo], 0, 2\n\t"
         "v_cmp_eq_u32_e64 s[36:37], %[vt], 2\n\t"
@@ -1173,16 +1174,14 @@ __device__ __forceinline__ uint32_t walk_window(const uint32_t Flo, const uint32
         "v_bfe_u32 %[vt], %[fhi], 30, 2\n\t"
         "v_cmp_eq_u32_e64 s[98:99], %[vt], 2\n\t"
         "s_nop 3\n\t"
-        "s_add_i32 %[t0], %[o], 16\n\t"
-        "Ltop_%=:\n\t"                      // t0 = o + 16 here, from above or from the bottom of the round
-        "s_lshl_b32 m0, %[t0], 1\n\t"
-        "s_nop 0\n\t"
+        "s_add_i32 %[o], %[o], 16\n\t"      // the loop keeps o + 16 (the mask's index)
+        "Ltop_%=:\n\t"
+        "s_lshl_b32 m0, %[o], 1\n\t"
+        "s_sub_i32 %[t1], 64, %[d]\n\t"     // (also the wait state between the write of M0 and s_movrels)
         "s_movrels_b64 vcc, s[36:37]\n\t"
         "s_lshr_b64 vcc, vcc, %[d]\n\t"
-        "s_not_b64 vcc, vcc\n\t"
-        "s_ff1_i32_b64 %[L], vcc\n\t"
-        "s_sub_i32 %[t1], 64, %[d]\n\t"     // d = 64 can arrive here (an up move out of the last row): the shift was by 0 then
-        "s_min_u32 %[L], %[L], %[t1]\n\t"
+        "s_ff0_i32_b64 %[L], vcc\n\t"       // -1 (no zero: d = 0 and 64 diagonal moves) is the largest unsigned value
+        "s_min_u32 %[L], %[L], %[t1]\n\t"   // d = 64 can arrive here (an up move out of the last row): the shift was by 0 then
         "s_add_i32 %[k], %[k], %[L]\n\t"
         "s_add_i32 %[d], %[d], %[L]\n\t"
         "s_cmp_ge_i32 %[k], 32\n\t"
@@ -1193,18 +1192,14 @@ __device__ __forceinline__ uint32_t walk_window(const uint32_t Flo, const uint32
         "v_readlane_b32 vcc_hi, %[fhi], %[d]\n\t"
         "v_readlane_b32 vcc_lo, %[flo], %[d]\n\t"
         "s_lshr_b64 vcc, vcc, m0\n\t"         // M0 is still 2 (o + 16): the row's code at this drift
-        "s_and_b32 %[c], vcc_lo, 3\n\t"
-        "s_cmp_eq_u32 %[c], 3\n\t"
-        "s_cbranch_scc1 Lout_%=\n\t"
-        "s_sub_i32 %[t1], 1, %[c]\n\t"          // 1 for an up move (op 2, tag F = 0), 0 for a left move (op 1, tag E = 1)
+        "s_andn2_b32 %[t1], 1, vcc_lo\n\t"     // tag F = 0: up (1), tag E = 1: left (0); NW has no other code off the diagonal
         "s_lshl1_add_u32 %[t0], %[k], %[t1]\n\t"
         "s_bitset1_b64 %[acc], %[t0]\n\t"       // the op is one set bit of the move's two: 2k (left) or 2k + 1 (up)
         "s_add_i32 %[k], %[k], 1\n\t"
         "s_add_i32 %[d], %[d], %[t1]\n\t"
         "s_lshl1_add_u32 %[o], %[t1], %[o]\n\t"
         "s_add_i32 %[o], %[o], -1\n\t"
-        "s_add_i32 %[t0], %[o], 16\n\t"
-        "s_cmp_lt_u32 %[t0], 32\n\t"
+        "s_cmp_lt_u32 %[o], 32\n\t"
         "s_cbranch_scc1 Ltop_%=\n\t"
         "s_branch Lout_%=\n\t"
         "Lword_%=:\n\t"                       // a word of 32 moves is full: stage it, start the next
@@ -1217,11 +1212,125 @@ __device__ __forceinline__ uint32_t walk_window(const uint32_t Flo, const uint32
         "s_cbranch_scc1 Lword_%=\n\t"
         "s_branch Lback_%=\n\t"
         "Lout_%=:\n\t"
+        "s_add_i32 %[o], %[o], -16\n\t"
         : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [c] "+s"(c), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L),
           [saddr] "+v"(saddr), [wtmp] "=&v"(wtmp), [vt] "=&v"(vt)
         : [flo] "v"(Flo), [fhi] "v"(Fhi)
         : "scc", "vcc", "memory", SA_WALK_MASK_CLOBBERS);
-  } else {  // LCS cell kernels: codes 3 diagonal, 2 up, 1 left are the ops themselves; there is no stop code
+  } else if constexpr (CODES == 2) {
+    asm volatile(
+        "v_bfe_u32 %[vt], %[flo], 0, 2\n\t"
+        "v_cmp_eq_u32_e64 s[36:37], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 2, 2\n\t"
+        "v_cmp_eq_u32_e64 s[38:39], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 4, 2\n\t"
+        "v_cmp_eq_u32_e64 s[40:41], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 6, 2\n\t"
+        "v_cmp_eq_u32_e64 s[42:43], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 8, 2\n\t"
+        "v_cmp_eq_u32_e64 s[44:45], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 10, 2\n\t"
+        "v_cmp_eq_u32_e64 s[46:47], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 12, 2\n\t"
+        "v_cmp_eq_u32_e64 s[48:49], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 14, 2\n\t"
+        "v_cmp_eq_u32_e64 s[50:51], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 16, 2\n\t"
+        "v_cmp_eq_u32_e64 s[52:53], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 18, 2\n\t"
+        "v_cmp_eq_u32_e64 s[54:55], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 20, 2\n\t"
+        "v_cmp_eq_u32_e64 s[56:57], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 22, 2\n\t"
+        "v_cmp_eq_u32_e64 s[58:59], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 24, 2\n\t"
+        "v_cmp_eq_u32_e64 s[60:61], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 26, 2\n\t"
+        "v_cmp_eq_u32_e64 s[62:63], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 28, 2\n\t"
+        "v_cmp_eq_u32_e64 s[64:65], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[flo], 30, 2\n\t"
+        "v_cmp_eq_u32_e64 s[66:67], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 0, 2\n\t"
+        "v_cmp_eq_u32_e64 s[68:69], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 2, 2\n\t"
+        "v_cmp_eq_u32_e64 s[70:71], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 4, 2\n\t"
+        "v_cmp_eq_u32_e64 s[72:73], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 6, 2\n\t"
+        "v_cmp_eq_u32_e64 s[74:75], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 8, 2\n\t"
+        "v_cmp_eq_u32_e64 s[76:77], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 10, 2\n\t"
+        "v_cmp_eq_u32_e64 s[78:79], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 12, 2\n\t"
+        "v_cmp_eq_u32_e64 s[80:81], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 14, 2\n\t"
+        "v_cmp_eq_u32_e64 s[82:83], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 16, 2\n\t"
+        "v_cmp_eq_u32_e64 s[84:85], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 18, 2\n\t"
+        "v_cmp_eq_u32_e64 s[86:87], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 20, 2\n\t"
+        "v_cmp_eq_u32_e64 s[88:89], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 22, 2\n\t"
+        "v_cmp_eq_u32_e64 s[90:91], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 24, 2\n\t"
+        "v_cmp_eq_u32_e64 s[92:93], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 26, 2\n\t"
+        "v_cmp_eq_u32_e64 s[94:95], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 28, 2\n\t"
+        "v_cmp_eq_u32_e64 s[96:97], %[vt], 2\n\t"
+        "v_bfe_u32 %[vt], %[fhi], 30, 2\n\t"
+        "v_cmp_eq_u32_e64 s[98:99], %[vt], 2\n\t"
+        "s_nop 3\n\t"
+        "s_add_i32 %[o], %[o], 16\n\t"      // the loop keeps o + 16 (the mask's index)
+        "Ltop_%=:\n\t"
+        "s_lshl_b32 m0, %[o], 1\n\t"
+        "s_sub_i32 %[t1], 64, %[d]\n\t"     // (also the wait state between the write of M0 and s_movrels)
+        "s_movrels_b64 vcc, s[36:37]\n\t"
+        "s_lshr_b64 vcc, vcc, %[d]\n\t"
+        "s_ff0_i32_b64 %[L], vcc\n\t"       // -1 (no zero: d = 0 and 64 diagonal moves) is the largest unsigned value
+        "s_min_u32 %[L], %[L], %[t1]\n\t"   // d = 64 can arrive here (an up move out of the last row): the shift was by 0 then
+        "s_add_i32 %[k], %[k], %[L]\n\t"
+        "s_add_i32 %[d], %[d], %[L]\n\t"
+        "s_cmp_ge_i32 %[k], 32\n\t"
+        "s_cbranch_scc1 Lword_%=\n\t"
+        "Lback_%=:\n\t"
+        "s_cmp_ge_i32 %[d], 64\n\t"
+        "s_cbranch_scc1 Lout_%=\n\t"
+        "v_readlane_b32 vcc_hi, %[fhi], %[d]\n\t"
+        "v_readlane_b32 vcc_lo, %[flo], %[d]\n\t"
+        "s_lshr_b64 vcc, vcc, m0\n\t"         // M0 is still 2 (o + 16): the row's code at this drift
+        "s_and_b32 %[c], vcc_lo, 3\n\t"
+        "s_cmp_eq_u32 %[c], 3\n\t"             // SW's stop cell
+        "s_cbranch_scc1 Lout_%=\n\t"
+        "s_sub_i32 %[t1], 1, %[c]\n\t"          // 1 for an up move (tag F = 0), 0 for a left move (tag E = 1)
+        "s_lshl1_add_u32 %[t0], %[k], %[t1]\n\t"
+        "s_bitset1_b64 %[acc], %[t0]\n\t"       // the op is one set bit of the move's two: 2k (left) or 2k + 1 (up)
+        "s_add_i32 %[k], %[k], 1\n\t"
+        "s_add_i32 %[d], %[d], %[t1]\n\t"
+        "s_lshl1_add_u32 %[o], %[t1], %[o]\n\t"
+        "s_add_i32 %[o], %[o], -1\n\t"
+        "s_cmp_lt_u32 %[o], 32\n\t"
+        "s_cbranch_scc1 Ltop_%=\n\t"
+        "s_branch Lout_%=\n\t"
+        "Lword_%=:\n\t"                       // a word of 32 moves is full: stage it, start the next
+        "v_mov_b64 %[wtmp], %[acc]\n\t"
+        "ds_write_b64 %[saddr], %[wtmp]\n\t"
+        "v_add_u32 %[saddr], 8, %[saddr]\n\t"
+        "s_mov_b64 %[acc], 0\n\t"
+        "s_sub_i32 %[k], %[k], 32\n\t"
+        "s_cmp_ge_i32 %[k], 32\n\t"
+        "s_cbranch_scc1 Lword_%=\n\t"
+        "s_branch Lback_%=\n\t"
+        "Lout_%=:\n\t"
+        "s_add_i32 %[o], %[o], -16\n\t"
+        : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [c] "+s"(c), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L),
+          [saddr] "+v"(saddr), [wtmp] "=&v"(wtmp), [vt] "=&v"(vt)
+        : [flo] "v"(Flo), [fhi] "v"(Fhi)
+        : "scc", "vcc", "memory", SA_WALK_MASK_CLOBBERS);
+  } else {
     asm volatile(
         "v_bfe_u32 %[vt], %[flo], 0, 2\n\t"
         "v_cmp_eq_u32_e64 s[36:37], %[vt], 3\n\t"
@@ -1288,16 +1397,14 @@ __device__ __forceinline__ uint32_t walk_window(const uint32_t Flo, const uint32
         "v_bfe_u32 %[vt], %[fhi], 30, 2\n\t"
         "v_cmp_eq_u32_e64 s[98:99], %[vt], 3\n\t"
         "s_nop 3\n\t"
-        "s_add_i32 %[t0], %[o], 16\n\t"
-        "Ltop_%=:\n\t"                      // t0 = o + 16 here, from above or from the bottom of the round
-        "s_lshl_b32 m0, %[t0], 1\n\t"
-        "s_nop 0\n\t"
+        "s_add_i32 %[o], %[o], 16\n\t"      // the loop keeps o + 16 (the mask's index)
+        "Ltop_%=:\n\t"
+        "s_lshl_b32 m0, %[o], 1\n\t"
+        "s_sub_i32 %[t1], 64, %[d]\n\t"     // (also the wait state between the write of M0 and s_movrels)
         "s_movrels_b64 vcc, s[36:37]\n\t"
         "s_lshr_b64 vcc, vcc, %[d]\n\t"
-        "s_not_b64 vcc, vcc\n\t"
-        "s_ff1_i32_b64 %[L], vcc\n\t"
-        "s_sub_i32 %[t1], 64, %[d]\n\t"     // d = 64 can arrive here (an up move out of the last row): the shift was by 0 then
-        "s_min_u32 %[L], %[L], %[t1]\n\t"
+        "s_ff0_i32_b64 %[L], vcc\n\t"       // -1 (no zero: d = 0 and 64 diagonal moves) is the largest unsigned value
+        "s_min_u32 %[L], %[L], %[t1]\n\t"   // d = 64 can arrive here (an up move out of the last row): the shift was by 0 then
         "s_add_i32 %[k], %[k], %[L]\n\t"
         "s_add_i32 %[d], %[d], %[L]\n\t"
         "s_cmp_ge_i32 %[k], 32\n\t"
@@ -1315,8 +1422,7 @@ __device__ __forceinline__ uint32_t walk_window(const uint32_t Flo, const uint32
         "s_add_i32 %[d], %[d], %[t1]\n\t"
         "s_lshl1_add_u32 %[o], %[t1], %[o]\n\t"
         "s_add_i32 %[o], %[o], -1\n\t"
-        "s_add_i32 %[t0], %[o], 16\n\t"
-        "s_cmp_lt_u32 %[t0], 32\n\t"
+        "s_cmp_lt_u32 %[o], 32\n\t"
         "s_cbranch_scc1 Ltop_%=\n\t"
         "s_branch Lout_%=\n\t"
         "Lword_%=:\n\t"                       // a word of 32 moves is full: stage it, start the next
@@ -1329,6 +1435,7 @@ __device__ __forceinline__ uint32_t walk_window(const uint32_t Flo, const uint32
         "s_cbranch_scc1 Lword_%=\n\t"
         "s_branch Lback_%=\n\t"
         "Lout_%=:\n\t"
+        "s_add_i32 %[o], %[o], -16\n\t"
         : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [c] "+s"(c), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L),
           [saddr] "+v"(saddr), [wtmp] "=&v"(wtmp), [vt] "=&v"(vt)
         : [flo] "v"(Flo), [fhi] "v"(Fhi)
@@ -1377,16 +1484,14 @@ __device__ __forceinline__ void walk_window_bits(const uint32_t (&yv)[8], const 
       "v_cmp_eq_u32_sdwa s[96:97], %[y7], %[xv] src0_sel:BYTE_2 src1_sel:DWORD\n\t"
       "v_cmp_eq_u32_sdwa s[98:99], %[y7], %[xv] src0_sel:BYTE_3 src1_sel:DWORD\n\t"
       "s_nop 3\n\t"
-      "s_add_i32 %[t0], %[o], 16\n\t"
+      "s_add_i32 %[o], %[o], 16\n\t"      // the loop keeps o + 16 (the mask's index)
       "Ltop_%=:\n\t"
-      "s_lshl_b32 m0, %[t0], 1\n\t"
-      "s_nop 0\n\t"
+      "s_lshl_b32 m0, %[o], 1\n\t"
+      "s_sub_i32 %[t1], 64, %[d]\n\t"     // (also the wait state between the write of M0 and s_movrels)
       "s_movrels_b64 vcc, s[36:37]\n\t"
       "s_lshr_b64 vcc, vcc, %[d]\n\t"
-      "s_not_b64 vcc, vcc\n\t"
-      "s_ff1_i32_b64 %[L], vcc\n\t"
-      "s_sub_i32 %[t1], 64, %[d]\n\t"
-      "s_min_u32 %[L], %[L], %[t1]\n\t"
+      "s_ff0_i32_b64 %[L], vcc\n\t"       // -1 (no zero: d = 0 and 64 diagonal moves) is the largest unsigned value
+      "s_min_u32 %[L], %[L], %[t1]\n\t"   // d = 64 can arrive here (an up move out of the last row): the shift was by 0 then
       "s_add_i32 %[k], %[k], %[L]\n\t"
       "s_add_i32 %[d], %[d], %[L]\n\t"
       "s_cmp_ge_i32 %[k], 32\n\t"
@@ -1394,7 +1499,7 @@ __device__ __forceinline__ void walk_window_bits(const uint32_t (&yv)[8], const 
       "Lback_%=:\n\t"
       "s_cmp_ge_i32 %[d], 64\n\t"
       "s_cbranch_scc1 Lout_%=\n\t"
-      "s_sub_i32 %[t0], 79, %[d]\n\t"
+      "s_sub_i32 %[t0], 63, %[d]\n\t"       // column j0 - d + o: lane 79 - d + o of ca, or of cb when that is 64 or more
       "s_add_i32 %[t0], %[t0], %[o]\n\t"
       "v_readlane_b32 vcc_hi, %[cahi], %[t0]\n\t"
       "v_readlane_b32 vcc_lo, %[calo], %[t0]\n\t"
@@ -1406,16 +1511,15 @@ __device__ __forceinline__ void walk_window_bits(const uint32_t (&yv)[8], const 
       "s_lshr_b64 vcc, vcc, %[d]\n\t"
       "s_and_b32 %[t1], vcc_lo, 1\n\t"          // set: up (op 2), clear: left (op 1)
       "s_lshl1_add_u32 %[t0], %[k], %[t1]\n\t"
-      "s_bitset1_b64 %[acc], %[t0]\n\t"
+      "s_bitset1_b64 %[acc], %[t0]\n\t"       // the op is one set bit of the move's two: 2k (left) or 2k + 1 (up)
       "s_add_i32 %[k], %[k], 1\n\t"
       "s_add_i32 %[d], %[d], %[t1]\n\t"
       "s_lshl1_add_u32 %[o], %[t1], %[o]\n\t"
       "s_add_i32 %[o], %[o], -1\n\t"
-      "s_add_i32 %[t0], %[o], 16\n\t"
-      "s_cmp_lt_u32 %[t0], 32\n\t"
+      "s_cmp_lt_u32 %[o], 32\n\t"
       "s_cbranch_scc1 Ltop_%=\n\t"
       "s_branch Lout_%=\n\t"
-      "Lword_%=:\n\t"
+      "Lword_%=:\n\t"                       // a word of 32 moves is full: stage it, start the next
       "v_mov_b64 %[wtmp], %[acc]\n\t"
       "ds_write_b64 %[saddr], %[wtmp]\n\t"
       "v_add_u32 %[saddr], 8, %[saddr]\n\t"
@@ -1425,6 +1529,7 @@ __device__ __forceinline__ void walk_window_bits(const uint32_t (&yv)[8], const 
       "s_cbranch_scc1 Lword_%=\n\t"
       "s_branch Lback_%=\n\t"
       "Lout_%=:\n\t"
+      "s_add_i32 %[o], %[o], -16\n\t"
       : [d] "+s"(dcur), [o] "+s"(o), [k] "+s"(k), [acc] "+s"(acc), [t0] "=&s"(t0), [t1] "=&s"(t1), [L] "=&s"(L), [saddr] "+v"(saddr),
         [wtmp] "=&v"(wtmp)
       : [y0] "v"(yv[0]), [y1] "v"(yv[1]), [y2] "v"(yv[2]), [y3] "v"(yv[3]), [y4] "v"(yv[4]), [y5] "v"(yv[5]), [y6] "v"(yv[6]), [y7] "v"(yv[7]),
@@ -1433,11 +1538,11 @@ __device__ __forceinline__ void walk_window_bits(const uint32_t (&yv)[8], const 
 }
 
 // BITS: the bit-vector LCS format above instead of 2-bit codes (bands: the record starts with row i_min's strip).
-// TAGGED: NW / SW codes (the winner's tag) as opposed to the LCS cell kernels' pointers; a template parameter, because the
-// two window loops as branches of one function leave the register allocator with SGPR values it cannot place.
-template <bool BITS, bool TAGGED = false>
+// CODES: what the 2-bit codes are (walk_window): the LCS cell kernels' pointers, NW tags, SW tags; a template parameter,
+// because the window loops as branches of one function leave the register allocator with SGPR values it cannot place.
+template <bool BITS, int CODES = 0>
 __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
-  static_assert(!(BITS && TAGGED), "the bit-vector record is LCS only");
+  static_assert(!(BITS && CODES != 0), "the bit-vector record is LCS only");
   // The packed moves are staged in LDS and written out in bulk: with no global stores inside the walk, the
   // only vector-memory operations in flight are the loads of the NEXT window, so waiting for them
   // at the top of the next round (vmcnt counts loads and stores together, in order) waits for
@@ -1445,7 +1550,7 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
   __shared__ unsigned long long stage[kTraceStageWords];
   __shared__ __attribute__((aligned(16))) uint8_t ywin[BITS ? 128 : 16];  // BITS: the target symbols of the window's 96 columns
   const int d = threadIdx.x;
-  constexpr bool tagged = TAGGED;
+  constexpr bool tagged = CODES != 0;
   int lgK = 0;
   while ((1 << lgK) < a.K) ++lgK;
   int i = a.m, j = a.n;
@@ -1572,7 +1677,7 @@ __global__ void __launch_bounds__(64) traceback_walk(const TraceArgs a) {
         if constexpr (BITS)
           walk_window_bits(yvs, w.xv, ca_lo, ca_hi, cb_lo, cb_hi, dcur, o, k, acc, saddr);
         else
-          c = walk_window<TAGGED>(Flo, Fhi, dcur, o, k, acc, saddr);
+          c = walk_window<CODES>(Flo, Fhi, dcur, o, k, acc, saddr);
         while (k >= 32) {  // the loop was left right after the move that filled a word
           stage[((uint32_t)__builtin_amdgcn_readfirstlane((int)saddr) - stage0) >> 3] = acc;  // all lanes, same word, same place
           saddr += 8;

@@ -359,7 +359,7 @@ void bits_launch_fill(hipStream_t st, int grid_blocks, int waves_per_block, cons
 }
 
 void bits_launch_traceback(hipStream_t st, const TraceArgs& t) {
-  hipLaunchKernelGGL((traceback_walk<true, false>), dim3(1), dim3(64), 0, st, t);
+  hipLaunchKernelGGL((traceback_walk<true, 0>), dim3(1), dim3(64), 0, st, t);
 }
 
 }  // namespace sa

@@ -986,10 +986,12 @@ int lcs_bits_fill(sa_ctx* ctx, const uint8_t* x, int m, const uint8_t* y, int n,
 
 // the walker over 2-bit codes: NW / SW tags or the LCS cell kernels' pointers
 static void launch_traceback_walk(hipStream_t st, const TraceArgs& t) {
-  if (t.kind != KIND_LCS)
-    hipLaunchKernelGGL((traceback_walk<false, true>), dim3(1), dim3(64), 0, st, t);
+  if (t.kind == KIND_NW)
+    hipLaunchKernelGGL((traceback_walk<false, 1>), dim3(1), dim3(64), 0, st, t);
+  else if (t.kind == KIND_SW)
+    hipLaunchKernelGGL((traceback_walk<false, 2>), dim3(1), dim3(64), 0, st, t);
   else
-    hipLaunchKernelGGL((traceback_walk<false, false>), dim3(1), dim3(64), 0, st, t);
+    hipLaunchKernelGGL((traceback_walk<false, 0>), dim3(1), dim3(64), 0, st, t);
 }
 
 // Traceback after a checkpointed fill: from the start cell upwards, recompute the codes of `band`
