@@ -145,8 +145,11 @@ pair("1m", "void sa::fill_persistent<0, 8, 0>", 1_000_000, 999_747, 8, 12)
 pair("100k", "void sa::fill_persistent<0, 2, 0>", 100_000, 100_085, 2, 12, args=" --size 100000")
 pair("sw1m", "void sa::fill_persistent<1, 8, 0>", 1_000_000, 999_747, 8, 14, label="sw1m", args=" --kind sw")
 # the second wave per SIMD: the same pair on fill_group with two workgroups per CU, and on one
-pair("1m_group_wps2", "void sa::fill_group<0, 8, 0>", 1_000_000, 999_747, 8, 12, label="nw1m_group_wps2", note="SA_GROUP=1 SA_WPS=2 ")
-pair("1m_group_wps1", "void sa::fill_group<0, 8, 0>", 1_000_000, 999_747, 8, 12, label="nw1m_group_wps1", note="SA_GROUP=1 SA_WPS=1 ")
+for wps in (2, 1):
+    try:
+        pair(f"1m_group_wps{wps}", "void sa::fill_group<0, 8, 0>", 1_000_000, 999_747, 8, 12, label=f"nw1m_group_wps{wps}", note=f"SA_GROUP=1 SA_WPS={wps} ")
+    except StopIteration:  # (a stats-only refresh, `profile_r03.sh s`, does not run the fill_group pair)
+        print(f"1m_group_wps{wps}: not in this collection, profiles/ keeps the earlier files")
 for tag, dst in (("100k_unrel", "nw100k_unrelated"), ("2m", "nw2m_checkpointed"), ("lcs2m", "lcs2m_checkpointed"), ("1m_unrel", "nw1m_unrelated")):
     st, f = stats(f"stats_{tag}")
     shutil.copy(f, DST / f"r03_{dst}_kernel_stats.csv")
