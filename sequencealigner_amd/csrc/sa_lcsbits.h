@@ -9,6 +9,14 @@ namespace sa {
 constexpr int kBitsRowsPerLane = 32;                      // one dword of vertical differences per lane
 constexpr int kBitsStripRows = 64 * kBitsRowsPerLane;     // 2048 rows per strip (wavefront)
 constexpr int kBitsSub = 32;                              // steps between record hand-offs (16 or 32)
+#ifndef SA_BITS_STORE_REGS
+#define SA_BITS_STORE_REGS 16
+#endif
+// Registers the record dwords of consecutive steps rotate through.  A store's four are not written again before
+// kBitsStoreRegs - 3 steps have passed: a VALU write to a register that a store in front of it has not read yet stalls the
+// wave until the memory pipeline has taken the data, and with four registers (rewritten two steps after the store) that
+// stall was 4 ns of a lone strip's 31 ns per step (one strip of 1 M columns: 31.5 -> 27.5 ms with its record, 25.4 without).
+constexpr int kBitsStoreRegs = SA_BITS_STORE_REGS;
 constexpr int kBitsRecord0 = 256;                         // index of column 0 in a slot of hand-off records
 constexpr int kBitsMaxAlpha = 256;                        // profile symbols incl. the padding symbol (codes are bytes): 256 B of LDS each per wave
 constexpr int kBitsLdsBytes = 160 * 1024;                 // LDS of a CU (gfx950); a workgroup's waves share it

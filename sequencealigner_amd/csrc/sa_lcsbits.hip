@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
         inb = (uint32_t)__builtin_amdgcn_readfirstlane((int)inb);
         unsigned long long cos[16];
         uint32_t vrec = 0;
-        uint32_t Vh[4];
+        uint32_t Vh[kBitsStoreRegs];
 #pragma unroll
         for (int u = 0; u < SUBN; ++u) {
           // One step: U = V & M; V' = (V + U + carry) | (V & ~M), the carry-in mask being the carry-out mask of
@@ -190,9 +190,10 @@ __global__ void __launch_bounds__(64 * kWavesPerBlock) lcs_bits_persistent(const
           // the record leaves four steps at a time, [strip][step / 4][lane][step % 4]: 1 KB in one piece per store
           // instruction (a quarter of the memory operations of a dword per step; 16 steps at a time as 4 x 16 bytes at a
           // 64-byte lane stride measured 70 ms against 47: every instruction then touches 64 lines in part)
-          Vh[u & 3] = V;
+          Vh[u % kBitsStoreRegs] = V;
           if (TRACE && (u & 3) == 3) {
-            const u32x4 v4 = {Vh[0], Vh[1], Vh[2], Vh[3]};
+            const int q0 = (u % kBitsStoreRegs) & ~3;  // the quad that just filled up (u is a constant once unrolled)
+            const u32x4 v4 = {Vh[q0], Vh[q0 + 1], Vh[q0 + 2], Vh[q0 + 3]};
             __builtin_nontemporal_store(v4, reinterpret_cast<u32x4*>((u < 16 ? tdst : tdst2) + ((u & 15) >> 2) * 256));  // offsets reach 4 KB
           }
           yb = nyb;
