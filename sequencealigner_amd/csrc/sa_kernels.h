@@ -1067,13 +1067,32 @@ __device__ __forceinline__ BitsWindow load_bits_window(const TraceArgs& a, int i
   const int glast = (((a.start_i >= 0 ? a.start_i : a.m) + 2047) / 2048) * 64 - 1;
   const int g1 = g0 + 1, g2 = min(g0 + 2, glast);
   const int cA = j0 - 80 + q, cB = min(j0 - 16 + q, a.n - 1);
+  // Addresses as in bits_word, with what the six of a window share computed once (the walker is bound by instruction
+  // issue: ~105 instructions of address arithmetic per window before, ~55 now): the three words are in the strip of the
+  // first or in the one after it, and everything is unsigned 32-bit but for one 32 x 32 -> 64 multiply.
+  const uint32_t rec = (uint32_t)a.W * 64u + (uint32_t)kBitsStripPad;  // dwords of a strip's record (< 2^32: host)
+  const uint32_t* base0 = a.trace + (size_t)(uint32_t)((g0 >> 6) - (a.i_min >> 11)) * rec;
+  const uint32_t* base1 = base0 + ((g1 >> 6) != (g0 >> 6) ? rec : 0u);
+  const uint32_t* base2 = base0 + ((g2 >> 6) != (g0 >> 6) ? rec : 0u);
+  const uint32_t l0 = (uint32_t)g0 & 63u, l1 = (uint32_t)g1 & 63u, l2 = (uint32_t)g2 & 63u;
+  auto off = [](uint32_t c, uint32_t l) {
+    const uint32_t t = c + (uint32_t)kBitsSkew * l;
+    return ((t & ~3u) << 6) + (t & 3u) + l * 4u;
+  };
+  const uint32_t oa0 = off((uint32_t)cA, l0), oa1 = off((uint32_t)cA, l1), oa2 = off((uint32_t)cA, l2);
+  uint32_t ob0, ob1, ob2;
+  if (j0 + 47 <= a.n - 1) {  // (wave-uniform) no lane's second column is clamped: it is 64 columns = 16 groups of four steps further on
+    ob0 = oa0 + 4096u, ob1 = oa1 + 4096u, ob2 = oa2 + 4096u;
+  } else {
+    ob0 = off((uint32_t)cB, l0), ob1 = off((uint32_t)cB, l1), ob2 = off((uint32_t)cB, l2);
+  }
   BitsWindow w;
-  w.a0 = bits_word(a, g0, cA);
-  w.a1 = bits_word(a, g1, cA);
-  w.a2 = bits_word(a, g2, cA);
-  w.b0 = bits_word(a, g0, cB);
-  w.b1 = bits_word(a, g1, cB);
-  w.b2 = bits_word(a, g2, cB);
+  w.a0 = base0[oa0];
+  w.a1 = base1[oa1];
+  w.a2 = base2[oa2];
+  w.b0 = base0[ob0];
+  w.b1 = base1[ob1];
+  w.b2 = base2[ob2];
   w.ya = a.ys[cA];
   w.yb = a.ys[cB];
   w.xv = a.xs[i - 1 - q];
