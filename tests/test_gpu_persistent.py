@@ -36,20 +36,25 @@ def test_persistent_tie_storms_and_protein(pengine, oracle, kind):
         check(kind, pengine, oracle, x, rand_seq(rng, 1900, PROT24), "protein", -11.0, -1.0)
 
 
-@pytest.mark.parametrize("wps", [1, 2, 4])
-def test_persistent_many_strips_wave_counts(pengine, oracle, wps):
-    """More strips than resident waves: every wave draws several tickets."""
+@pytest.fixture(scope="module")
+def many_strips_want(oracle):
+    """The oracle's NW and LCS of the 40 kb pair, once for the three wave counts (8 s of host time each)."""
     from sequencealigner_amd.synth import dna_pair
 
+    x, y = dna_pair(40000, seed=9)
+    return x, y, oracle.nw(x, y, "dna", packed=True), oracle.lcs(x, y, packed=True)
+
+
+@pytest.mark.parametrize("wps", [1, 2, 4])
+def test_persistent_many_strips_wave_counts(pengine, many_strips_want, wps):
+    """More strips than resident waves: every wave draws several tickets."""
+    x, y, o_nw, o_lcs = many_strips_want
     pengine.set_option("waves_per_simd", wps)
     pengine.set_tuning(1, 0)
-    x, y = dna_pair(40000, seed=9)
-    o = oracle.nw(x, y, "dna", packed=True)
     g = pengine.nw(x, y, "dna")
-    assert g.score == o.score and np.array_equal(g.ops, o.ops)
-    o = oracle.lcs(x, y, packed=True)
+    assert g.score == o_nw.score and np.array_equal(g.ops, o_nw.ops)
     g = pengine.lcs(x, y)
-    assert g.score == o.score and np.array_equal(g.ops, o.ops)
+    assert g.score == o_lcs.score and np.array_equal(g.ops, o_lcs.ops)
 
 
 def test_persistent_equals_launch_path_at_100k(engine):
